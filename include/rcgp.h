@@ -1,0 +1,90 @@
+/* rcgp.h -- C ABI of librcgp.so: MI355X (gfx950) backend for romcomma's GP-regression + closed-form Sobol hot path.
+ *
+ * The reference (romcomma @ 2024_08_07) has no FFI of its own: the path is Python calling GPflow/TensorFlow.
+ * Each entry point below replaces the GPflow/TF work behind one reference interface (paths relative to romcomma/):
+ *
+ *   rcgp_create / rcgp_set_y      GPR.__init__ pulling X (N,M), Y (N,L) from the Fold           gpr/models.py:306-308
+ *                                 + MOGP.implementation (one gf.models.GPR per output)          gpr/models.py:340-342
+ *   rcgp_set_hyper                RBF.implementation / Likelihood (variance, lengthscales, noise) gpr/kernels.py:172-177, gpr/models.py:341
+ *   rcgp_lml, rcgp_lml_grad       gp.training_loss closure handed to gf.optimizers.Scipy          gpr/models.py:359-361
+ *                                 + gp.log_marginal_likelihood()                                  gpr/models.py:365,370
+ *   rcgp_factor                   MOGP.K_cho (Gram + noise + Cholesky), cached                    gpr/models.py:427-439
+ *   rcgp_get_k_cho                MOGP.K_cho value for one output, (N,N) lower                    gpr/models.py:427-439
+ *   rcgp_get_k_inv_y              MOGP.K_inv_Y for one output, (N,)                               gpr/models.py:441-444
+ *   rcgp_predict                  MOGP.predict -> gp.predict_y / predict_f (mean, SD)             gpr/models.py:375-384
+ *   rcgp_sobol_closed             ClosedSobol._calibrate/_V/marginalize, diagonal (l = j) term    gsa/calibrators.py:49-97
+ *   rcgp_sobol_cross              the same einsum's off-diagonal (l != j) entries                 gsa/calibrators.py:79
+ *
+ * Conventions: all matrices row-major float64; the caller owns every host buffer; the library owns device memory inside
+ * the opaque handle until rcgp_destroy. A handle is bound to one device and one HIP stream; it is not thread-safe;
+ * distinct handles are independent. Return value: 0 = ok; k > 0 = LAPACK-style "leading minor k is not positive
+ * definite" (TensorFlow raises InvalidArgumentError there); < 0 = bad argument (-1..-9) or HIP error (-100 - hipError_t).
+ * rcgp_last_error gives the message. One process per GPU for multi-GPU runs.
+ */
+#ifndef RCGP_H
+#define RCGP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rcgp_handle_s* rcgp_handle;
+
+/* Library/ABI version (major*100 + minor). */
+int rcgp_version(void);
+/* Number of visible HIP devices, or a negative error. Does not create a context on any of them. */
+int rcgp_device_count(void);
+
+/* Upload the training fold: X is (N, M) row-major, y is (N). 1 <= M <= 64. */
+int rcgp_create(rcgp_handle* out, int device, int64_t N, int M, const double* X, const double* y);
+int rcgp_destroy(rcgp_handle h);
+const char* rcgp_last_error(rcgp_handle h);
+
+/* Replace the output column (same X): one handle can serve the L independent outputs in turn. */
+int rcgp_set_y(rcgp_handle h, const double* y);
+/* Hyper-parameters in the constrained space: lengthscales ell[M] (pass the isotropic value M times), kernel variance,
+ * likelihood (noise) variance. Invalidates any cached factor. */
+int rcgp_set_hyper(rcgp_handle h, const double* ell, double variance, double noise);
+
+/* Log marginal likelihood at the current hyper-parameters (Gram + Cholesky + forward solve). */
+int rcgp_lml(rcgp_handle h, double* lml);
+/* LML and its gradient w.r.t. (ell[0..M-1], variance, noise), constrained space; grad has M + 2 entries. */
+int rcgp_lml_grad(rcgp_handle h, double* lml, double* grad);
+
+/* Factor and cache L = chol(K + noise I), L^-1 and alpha = K^-1 y for predict / K_inv_Y / Sobol. */
+int rcgp_factor(rcgp_handle h);
+int rcgp_get_k_inv_y(rcgp_handle h, double* out /* N */);
+int rcgp_get_k_cho(rcgp_handle h, double* out /* N*N, lower, zeros above */);
+/* The Gram matrix K + noise I itself (lower triangle valid, upper mirrored), for tests. Invalidates the cached factor. */
+int rcgp_get_gram(rcgp_handle h, double* out /* N*N */);
+
+/* Posterior at n new points Xnew (n, M): mean[n] and standard deviation sd[n] (SD, not variance: gpr/models.py:384).
+ * include_noise != 0 is predict_y, 0 is predict_f. */
+int rcgp_predict(rcgp_handle h, int64_t n, const double* Xnew, int include_noise, double* mean, double* sd);
+
+/* Closed-form Sobol conditional variances for this handle's output: V[s] for each slice [slices[2s], slices[2s+1]) of
+ * the input dimensions (gsa/models.py:77-90). Requires rcgp_factor. */
+int rcgp_sobol_closed(rcgp_handle h, int n_slices, const int32_t* slices, double* V);
+/* Cross-output term V_lj: l = this handle's output, j given by its lengthscales ell_j[M], kernel variance var_j and
+ * alpha_j[N] = K_j^-1 y_j (from rcgp_get_k_inv_y of the other output, possibly gathered from another GPU). */
+int rcgp_sobol_cross(rcgp_handle h, const double* ell_j, double var_j, const double* alpha_j, int n_slices, const int32_t* slices,
+                     double* V);
+
+/* ---- stage-level entry points used by bench.py and the kernel tests ---- */
+int rcgp_stage_gram(rcgp_handle h);      /* Z = X/ell; A = K + noise I (lower tiles) */
+int rcgp_stage_potrf(rcgp_handle h);     /* blocked Cholesky in place + w = L^-1 y; requires rcgp_stage_gram */
+int rcgp_stage_trtri(rcgp_handle h);     /* L^-1 and alpha; requires rcgp_stage_potrf */
+int rcgp_sync(rcgp_handle h);
+
+/* ---- profiling: HIP events around every kernel launch on the handle's stream ---- */
+enum { RCGP_K_GRAM = 0, RCGP_K_GEMM = 1, RCGP_K_DIAG = 2, RCGP_K_SOBOL = 3, RCGP_K_MISC = 4, RCGP_K_COUNT = 5 };
+int rcgp_set_profiling(rcgp_handle h, int on);
+int rcgp_profile_reset(rcgp_handle h);
+/* For kernel class cls: number of launches, summed launch duration (ms) and summed ALGORITHMIC work since the last
+ * reset: bytes for GRAM, flops for GEMM and DIAG, exp evaluations for SOBOL. */
+int rcgp_profile_get(rcgp_handle h, int cls, int64_t* launches, double* total_ms, double* work);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,235 @@
+"""ctypes binding of librcgp.so (include/rcgp.h). There is no CPU fallback: if the HIP library is missing or no GPU is
+visible the calls raise, loudly."""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / 'librcgp.so'
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int32_p = ctypes.POINTER(ctypes.c_int32)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+
+# name -> (restype, argtypes); every symbol include/rcgp.h declares.
+SIGNATURES = {
+    'rcgp_version': (ctypes.c_int, []),
+    'rcgp_device_count': (ctypes.c_int, []),
+    'rcgp_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int64, ctypes.c_int, _c_double_p, _c_double_p]),
+    'rcgp_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'rcgp_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
+    'rcgp_set_y': (ctypes.c_int, [ctypes.c_void_p, _c_double_p]),
+    'rcgp_set_hyper': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, ctypes.c_double]),
+    'rcgp_lml': (ctypes.c_int, [ctypes.c_void_p, _c_double_p]),
+    'rcgp_lml_grad': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p]),
+    'rcgp_factor': (ctypes.c_int, [ctypes.c_void_p]),
+    'rcgp_get_k_inv_y': (ctypes.c_int, [ctypes.c_void_p, _c_double_p]),
+    'rcgp_get_k_cho': (ctypes.c_int, [ctypes.c_void_p, _c_double_p]),
+    'rcgp_get_gram': (ctypes.c_int, [ctypes.c_void_p, _c_double_p]),
+    'rcgp_predict': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    'rcgp_sobol_closed': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int32_p, _c_double_p]),
+    'rcgp_sobol_cross': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_int, _c_int32_p, _c_double_p]),
+    'rcgp_stage_gram': (ctypes.c_int, [ctypes.c_void_p]),
+    'rcgp_stage_potrf': (ctypes.c_int, [ctypes.c_void_p]),
+    'rcgp_stage_trtri': (ctypes.c_int, [ctypes.c_void_p]),
+    'rcgp_sync': (ctypes.c_int, [ctypes.c_void_p]),
+    'rcgp_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'rcgp_profile_reset': (ctypes.c_int, [ctypes.c_void_p]),
+    'rcgp_profile_get': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int64_p, _c_double_p, _c_double_p]),
+}
+
+K_GRAM, K_GEMM, K_DIAG, K_SOBOL, K_MISC = range(5)
+KERNEL_CLASS_NAMES = ('gram', 'gemm', 'diag', 'sobol', 'misc')
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class RcgpError(RuntimeError):
+    """A HIP / argument failure inside librcgp (negative status)."""
+
+
+class NotPositiveDefiniteError(ValueError):
+    """Cholesky failed: leading minor ``k`` is not positive definite (the reference raises tf InvalidArgumentError here)."""
+
+    def __init__(self, k: int, message: str):
+        super().__init__(message)
+        self.k = k
+
+
+def load() -> ctypes.CDLL:
+    """Load librcgp.so from the package directory (built in-tree by ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RcgpError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                            f'(or `make -C {_HERE / "csrc"}`). There is no CPU fallback.')
+        lib = ctypes.CDLL(str(LIB_PATH))
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = lib
+    return _lib
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f'expected shape {tuple(shape)}, got {a.shape}')
+    return a
+
+
+class RcGP:
+    """One independent-output GP resident on one GPU: a thin object wrapper around an ``rcgp_handle``."""
+
+    def __init__(self, X: np.ndarray, y: np.ndarray, device: int = 0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        X = _f64(X)
+        if X.ndim != 2:
+            raise ValueError('X must be (N, M)')
+        self.N, self.M = X.shape
+        y = _f64(y).reshape(-1)
+        if y.shape[0] != self.N:
+            raise ValueError('y must have N entries')
+        rc = self._lib.rcgp_create(ctypes.byref(self._h), int(device), self.N, self.M, _dp(X), _dp(y))
+        if rc != 0:
+            msg = self._lib.rcgp_last_error(None).decode()
+            self._h = ctypes.c_void_p()
+            raise RcgpError(f'rcgp_create failed ({rc}): {msg}')
+        self.device = int(device)
+
+    # -- plumbing
+    def _check(self, rc: int, what: str):
+        if rc == 0:
+            return
+        msg = self._lib.rcgp_last_error(self._h).decode()
+        if rc > 0:
+            raise NotPositiveDefiniteError(rc, f'{what}: {msg}')
+        raise RcgpError(f'{what} failed ({rc}): {msg}')
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.rcgp_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- data and hyper-parameters
+    def set_y(self, y):
+        y = _f64(y).reshape(-1)
+        if y.shape[0] != self.N:
+            raise ValueError('y must have N entries')
+        self._check(self._lib.rcgp_set_y(self._h, _dp(y)), 'rcgp_set_y')
+
+    def set_hyper(self, ell, variance: float, noise: float):
+        ell = np.ascontiguousarray(np.broadcast_to(np.asarray(ell, dtype=np.float64).reshape(-1), (self.M,)))
+        self._check(self._lib.rcgp_set_hyper(self._h, _dp(ell), float(variance), float(noise)), 'rcgp_set_hyper')
+
+    # -- the path
+    def lml(self) -> float:
+        out = ctypes.c_double()
+        self._check(self._lib.rcgp_lml(self._h, ctypes.byref(out)), 'rcgp_lml')
+        return out.value
+
+    def lml_grad(self) -> Tuple[float, np.ndarray]:
+        out = ctypes.c_double()
+        grad = np.empty(self.M + 2)
+        self._check(self._lib.rcgp_lml_grad(self._h, ctypes.byref(out), _dp(grad)), 'rcgp_lml_grad')
+        return out.value, grad
+
+    def factor(self):
+        self._check(self._lib.rcgp_factor(self._h), 'rcgp_factor')
+
+    def k_inv_y(self) -> np.ndarray:
+        out = np.empty(self.N)
+        self._check(self._lib.rcgp_get_k_inv_y(self._h, _dp(out)), 'rcgp_get_k_inv_y')
+        return out
+
+    def k_cho(self) -> np.ndarray:
+        out = np.empty((self.N, self.N))
+        self._check(self._lib.rcgp_get_k_cho(self._h, _dp(out)), 'rcgp_get_k_cho')
+        return out
+
+    def gram(self) -> np.ndarray:
+        out = np.empty((self.N, self.N))
+        self._check(self._lib.rcgp_get_gram(self._h, _dp(out)), 'rcgp_get_gram')
+        return out
+
+    def predict(self, Xnew, include_noise: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        Xnew = _f64(Xnew)
+        if Xnew.ndim != 2 or Xnew.shape[1] != self.M:
+            raise ValueError('Xnew must be (n, M)')
+        n = Xnew.shape[0]
+        mean, sd = np.empty(n), np.empty(n)
+        self._check(self._lib.rcgp_predict(self._h, n, _dp(Xnew), int(bool(include_noise)), _dp(mean), _dp(sd)), 'rcgp_predict')
+        return mean, sd
+
+    @staticmethod
+    def _slices(slices: Sequence[Sequence[int]]) -> np.ndarray:
+        s = np.ascontiguousarray(np.asarray(slices, dtype=np.int32).reshape(-1, 2))
+        return s
+
+    def sobol_closed(self, slices) -> np.ndarray:
+        s = self._slices(slices)
+        V = np.empty(s.shape[0])
+        self._check(self._lib.rcgp_sobol_closed(self._h, s.shape[0], s.ctypes.data_as(_c_int32_p), _dp(V)), 'rcgp_sobol_closed')
+        return V
+
+    def sobol_cross(self, ell_j, var_j: float, alpha_j, slices) -> np.ndarray:
+        s = self._slices(slices)
+        ell_j = np.ascontiguousarray(np.broadcast_to(np.asarray(ell_j, dtype=np.float64).reshape(-1), (self.M,)))
+        alpha_j = _f64(alpha_j).reshape(-1)
+        if alpha_j.shape[0] != self.N:
+            raise ValueError('alpha_j must have N entries')
+        V = np.empty(s.shape[0])
+        self._check(self._lib.rcgp_sobol_cross(self._h, _dp(ell_j), float(var_j), _dp(alpha_j), s.shape[0],
+                                               s.ctypes.data_as(_c_int32_p), _dp(V)), 'rcgp_sobol_cross')
+        return V
+
+    # -- stages and profiling (bench / kernel tests)
+    def stage_gram(self):
+        self._check(self._lib.rcgp_stage_gram(self._h), 'rcgp_stage_gram')
+
+    def stage_potrf(self):
+        self._check(self._lib.rcgp_stage_potrf(self._h), 'rcgp_stage_potrf')
+
+    def stage_trtri(self):
+        self._check(self._lib.rcgp_stage_trtri(self._h), 'rcgp_stage_trtri')
+
+    def sync(self):
+        self._check(self._lib.rcgp_sync(self._h), 'rcgp_sync')
+
+    def set_profiling(self, on: bool):
+        self._check(self._lib.rcgp_set_profiling(self._h, int(bool(on))), 'rcgp_set_profiling')
+
+    def profile_reset(self):
+        self._check(self._lib.rcgp_profile_reset(self._h), 'rcgp_profile_reset')
+
+    def profile_get(self, cls: int) -> Tuple[int, float, float]:
+        n, ms, work = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.rcgp_profile_get(self._h, int(cls), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work)),
+                    'rcgp_profile_get')
+        return n.value, ms.value, work.value
+
+
+def device_count() -> int:
+    return int(load().rcgp_device_count())

@@ -1,0 +1,369 @@
+// C ABI of librcgp.so (include/rcgp.h). Host-side orchestration only; kernels live in the sibling .hip files.
+#include "../../include/rcgp.h"
+#include "common.h"
+#include <math.h>
+#include <string.h>
+
+#define RC_API extern "C" __attribute__((visibility("default")))
+#define RC_CHECK_H(h)            \
+  if (!(h)) return -1;           \
+  if (hipSetDevice((h)->device) != hipSuccess) { (h)->err = "hipSetDevice failed"; return -3; }
+
+static const int64_t PRED_CAP = 4096;
+
+RC_API int rcgp_version(void) { return 100; }
+
+RC_API int rcgp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+static void free_all(rcgp_handle_s* h) {
+  double** bufs[] = {&h->X, &h->Z, &h->sq, &h->y, &h->w, &h->alpha, &h->A, &h->Linv, &h->S, &h->invdiag, &h->logdiag, &h->partial,
+                     &h->scal, &h->ell_d, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob};
+  for (auto b : bufs)
+    if (*b) { hipFree(*b); *b = nullptr; }
+  if (h->info) { hipFree(h->info); h->info = nullptr; }
+  for (auto& ev : h->prof_events) { hipEventDestroy(ev.start); hipEventDestroy(ev.stop); }
+  h->prof_events.clear();
+  if (h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
+}
+
+static std::string g_create_error;
+
+RC_API const char* rcgp_last_error(rcgp_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static int upload_padded(rcgp_handle_s* h, double* dst, const double* src, int64_t rows, int64_t rows_padded, int cols) {
+  RC_HIP(hipMemsetAsync(dst, 0, (size_t)rows_padded * cols * sizeof(double), h->stream));
+  RC_HIP(hipMemcpyAsync(dst, src, (size_t)rows * cols * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
+  const int64_t Np = h->Np;
+  const int M = h->M;
+  RC_HIP(hipSetDevice(h->device));
+  RC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  RC_HIP(hipMalloc(&h->X, (size_t)Np * M * sizeof(double)));
+  RC_HIP(hipMalloc(&h->Z, (size_t)Np * M * sizeof(double)));
+  RC_HIP(hipMalloc(&h->sq, (size_t)Np * sizeof(double)));
+  RC_HIP(hipMalloc(&h->y, (size_t)Np * sizeof(double)));
+  RC_HIP(hipMalloc(&h->w, (size_t)Np * sizeof(double)));
+  RC_HIP(hipMalloc(&h->alpha, (size_t)Np * sizeof(double)));
+  RC_HIP(hipMalloc(&h->A, (size_t)Np * Np * sizeof(double)));
+  RC_HIP(hipMalloc(&h->invdiag, (size_t)Np * 128 * sizeof(double)));
+  RC_HIP(hipMalloc(&h->logdiag, (size_t)Np * sizeof(double)));
+  RC_HIP(hipMalloc(&h->scal, 256 * sizeof(double)));
+  RC_HIP(hipMalloc(&h->info, sizeof(int)));
+  RC_HIP(hipMalloc(&h->ell_d, (size_t)M * sizeof(double)));
+  int rc;
+  if ((rc = upload_padded(h, h->X, X, h->N, Np, M))) return rc;
+  if ((rc = upload_padded(h, h->y, y, h->N, Np, 1))) return rc;
+  return 0;
+}
+
+RC_API int rcgp_create(rcgp_handle* out, int device, int64_t N, int M, const double* X, const double* y) {
+  if (!out) return -1;
+  *out = nullptr;
+  if (N < 1 || M < 1 || M > RC_MAX_M || !X || !y) { g_create_error = "rcgp_create: bad argument (need N>=1, 1<=M<=64, X, y)"; return -2; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "rcgp_create: no HIP device available"; return -4; }
+  if (device < 0 || device >= ndev) { g_create_error = "rcgp_create: device index out of range"; return -2; }
+  rcgp_handle_s* h = new rcgp_handle_s();
+  h->device = device;
+  h->N = N;
+  h->Np = ((N + RC_TILE - 1) / RC_TILE) * RC_TILE;
+  h->M = M;
+  h->ell.assign(M, 1.0);
+  int rc = create_impl(h, X, y);
+  if (rc) {
+    g_create_error = h->err;
+    free_all(h);
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+RC_API int rcgp_destroy(rcgp_handle h) {
+  if (!h) return -1;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  free_all(h);
+  delete h;
+  return 0;
+}
+
+RC_API int rcgp_set_y(rcgp_handle h, const double* y) {
+  RC_CHECK_H(h);
+  if (!y) { h->err = "rcgp_set_y: null y"; return -2; }
+  int rc = upload_padded(h, h->y, y, h->N, h->Np, 1);
+  h->factored = h->inverted = false;
+  return rc;
+}
+
+RC_API int rcgp_set_hyper(rcgp_handle h, const double* ell, double variance, double noise) {
+  RC_CHECK_H(h);
+  if (!ell) { h->err = "rcgp_set_hyper: null ell"; return -2; }
+  for (int m = 0; m < h->M; ++m)
+    if (!(ell[m] > 0.0) || !isfinite(ell[m])) { h->err = "rcgp_set_hyper: lengthscales must be positive and finite"; return -2; }
+  if (!(variance > 0.0) || !isfinite(variance) || !(noise >= 0.0) || !isfinite(noise)) {
+    h->err = "rcgp_set_hyper: variance must be > 0 and noise >= 0";
+    return -2;
+  }
+  h->ell.assign(ell, ell + h->M);
+  h->var = variance;
+  h->noise = noise;
+  RC_HIP(hipMemcpyAsync(h->ell_d, h->ell.data(), (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  h->hyper_set = true;
+  h->factored = h->inverted = false;
+  return 0;
+}
+
+static int need_hyper(rcgp_handle_s* h) {
+  if (!h->hyper_set) { h->err = "hyper-parameters not set: call rcgp_set_hyper first"; return -5; }
+  return 0;
+}
+
+static int do_gram(rcgp_handle_s* h) {
+  int rc;
+  if ((rc = rc_launch_scale(h))) return rc;
+  if ((rc = rc_launch_gram(h))) return rc;
+  h->factored = h->inverted = false;
+  return 0;
+}
+
+static int ensure_factor(rcgp_handle_s* h, bool want_inverse) {
+  int rc;
+  if ((rc = need_hyper(h))) return rc;
+  if (!h->factored) {
+    if ((rc = do_gram(h))) return rc;
+    if ((rc = rc_potrf(h))) return rc;
+  }
+  if (want_inverse && !h->inverted) {
+    if ((rc = rc_trtri(h))) return rc;
+    if ((rc = rc_alpha(h))) return rc;
+    h->inverted = true;
+  }
+  return 0;
+}
+
+RC_API int rcgp_stage_gram(rcgp_handle h) {
+  RC_CHECK_H(h);
+  int rc;
+  if ((rc = need_hyper(h))) return rc;
+  return do_gram(h);
+}
+
+RC_API int rcgp_stage_potrf(rcgp_handle h) {
+  RC_CHECK_H(h);
+  return rc_potrf(h);
+}
+
+RC_API int rcgp_stage_trtri(rcgp_handle h) {
+  RC_CHECK_H(h);
+  if (!h->factored) { h->err = "rcgp_stage_trtri: no Cholesky factor"; return -5; }
+  int rc;
+  if ((rc = rc_trtri(h))) return rc;
+  if ((rc = rc_alpha(h))) return rc;
+  h->inverted = true;
+  return 0;
+}
+
+RC_API int rcgp_sync(rcgp_handle h) {
+  RC_CHECK_H(h);
+  RC_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+RC_API int rcgp_lml(rcgp_handle h, double* lml) {
+  RC_CHECK_H(h);
+  if (!lml) return -2;
+  int rc;
+  if ((rc = ensure_factor(h, false))) return rc;
+  return rc_lml_value(h, lml);
+}
+
+RC_API int rcgp_lml_grad(rcgp_handle h, double* lml, double* grad) {
+  RC_CHECK_H(h);
+  if (!lml || !grad) return -2;
+  int rc;
+  if ((rc = ensure_factor(h, true))) return rc;
+  if ((rc = rc_lml_value(h, lml))) return rc;
+  int nrows = 0;
+  if ((rc = rc_launch_grad(h, &nrows))) return rc;
+  return rc_grad_finish(h, nrows, grad);
+}
+
+RC_API int rcgp_factor(rcgp_handle h) {
+  RC_CHECK_H(h);
+  int rc;
+  if ((rc = ensure_factor(h, true))) return rc;
+  double lml;
+  return rc_lml_value(h, &lml);          // synchronises and surfaces a non-PD failure
+}
+
+RC_API int rcgp_get_k_inv_y(rcgp_handle h, double* out) {
+  RC_CHECK_H(h);
+  if (!out) return -2;
+  int rc;
+  if ((rc = rcgp_factor(h))) return rc;
+  RC_HIP(hipMemcpyAsync(out, h->alpha, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static int copy_square(rcgp_handle_s* h, double* out) {
+  RC_HIP(hipMemcpy2DAsync(out, (size_t)h->N * sizeof(double), h->A, (size_t)h->Np * sizeof(double), (size_t)h->N * sizeof(double),
+                          (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+RC_API int rcgp_get_k_cho(rcgp_handle h, double* out) {
+  RC_CHECK_H(h);
+  if (!out) return -2;
+  int rc;
+  if ((rc = ensure_factor(h, false))) return rc;
+  double lml;
+  if ((rc = rc_lml_value(h, &lml))) return rc;
+  if ((rc = copy_square(h, out))) return rc;
+  const int64_t N = h->N;
+  for (int64_t i = 0; i < N; ++i) memset(out + i * N + i + 1, 0, (size_t)(N - i - 1) * sizeof(double));
+  return 0;
+}
+
+RC_API int rcgp_get_gram(rcgp_handle h, double* out) {
+  RC_CHECK_H(h);
+  if (!out) return -2;
+  int rc;
+  if ((rc = need_hyper(h))) return rc;
+  if ((rc = do_gram(h))) return rc;
+  if ((rc = copy_square(h, out))) return rc;
+  const int64_t N = h->N;
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t j = i + 1; j < N; ++j) out[i * N + j] = out[j * N + i];
+  return 0;
+}
+
+// mean[j] = sum_k KsT[j][k] alpha[k] : one block per test point, fixed-order tree
+__global__ void __launch_bounds__(256) k_rowdot(const double* __restrict__ KsT, int64_t ld, const double* __restrict__ alpha, int64_t n,
+                                                double* __restrict__ out) {
+  __shared__ double sm[256];
+  const double* row = KsT + (int64_t)blockIdx.x * ld;
+  double s = 0.0;
+  for (int64_t k = threadIdx.x; k < n; k += 256) s = fma(row[k], alpha[k], s);
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+
+RC_API int rcgp_predict(rcgp_handle h, int64_t n, const double* Xnew, int include_noise, double* mean, double* sd) {
+  RC_CHECK_H(h);
+  if (n < 0 || (n > 0 && (!Xnew || !mean || !sd))) { h->err = "rcgp_predict: bad argument"; return -2; }
+  int rc;
+  if ((rc = rcgp_factor(h))) return rc;
+  const int M = h->M;
+  const int64_t Np = h->Np;
+  if (!h->KsT) {
+    RC_HIP(hipMalloc(&h->Xs, (size_t)PRED_CAP * M * sizeof(double)));
+    RC_HIP(hipMalloc(&h->Zs, (size_t)PRED_CAP * M * sizeof(double)));
+    RC_HIP(hipMalloc(&h->sqs, (size_t)PRED_CAP * sizeof(double)));
+    RC_HIP(hipMalloc(&h->KsT, (size_t)PRED_CAP * Np * sizeof(double)));
+    RC_HIP(hipMalloc(&h->pmean, (size_t)PRED_CAP * sizeof(double)));
+    RC_HIP(hipMalloc(&h->pvar, (size_t)PRED_CAP * sizeof(double)));
+    h->pred_cap = PRED_CAP;
+  }
+  std::vector<double> hv(PRED_CAP);
+  for (int64_t o0 = 0; o0 < n; o0 += PRED_CAP) {
+    const int64_t nc = (n - o0 < PRED_CAP) ? n - o0 : PRED_CAP;
+    const int64_t ncp = ((nc + 127) / 128) * 128;
+    if ((rc = upload_padded(h, h->Xs, Xnew + o0 * M, nc, ncp, M))) return rc;
+    if ((rc = rc_launch_scale_rows(h, h->Xs, h->Zs, h->sqs, ncp))) return rc;
+    if ((rc = rc_launch_cross_gram(h, nc, ncp))) return rc;
+    {
+      RcProfScope ps(h, RC_K_MISC, 0.0);
+      hipLaunchKernelGGL(k_rowdot, dim3((unsigned)nc), dim3(256), 0, h->stream, h->KsT, Np, h->alpha, Np, h->pmean);
+      RC_HIP(hipGetLastError());
+    }
+    if ((rc = rc_launch_predict_var(h, ncp))) return rc;
+    RC_HIP(hipMemcpyAsync(mean + o0, h->pmean, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RC_HIP(hipMemcpyAsync(hv.data(), h->pvar, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RC_HIP(hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < nc; ++i) {
+      double v = h->var - hv[i];                       // k** - |L^-1 k*|^2  (GPflow base_conditional)
+      if (include_noise) v += h->noise;                // predict_y adds the likelihood variance
+      sd[o0 + i] = sqrt(v);                            // SD, not variance (gpr/models.py:384)
+    }
+  }
+  return 0;
+}
+
+RC_API int rcgp_sobol_closed(rcgp_handle h, int n_slices, const int32_t* slices, double* V) {
+  RC_CHECK_H(h);
+  if (n_slices < 0 || (n_slices > 0 && (!slices || !V))) { h->err = "rcgp_sobol_closed: bad argument"; return -2; }
+  int rc;
+  if ((rc = rcgp_factor(h))) return rc;
+  return rc_sobol(h, nullptr, 0.0, nullptr, n_slices, slices, V);
+}
+
+RC_API int rcgp_sobol_cross(rcgp_handle h, const double* ell_j, double var_j, const double* alpha_j, int n_slices, const int32_t* slices,
+                            double* V) {
+  RC_CHECK_H(h);
+  if (!ell_j || !alpha_j || n_slices < 0 || (n_slices > 0 && (!slices || !V))) { h->err = "rcgp_sobol_cross: bad argument"; return -2; }
+  for (int m = 0; m < h->M; ++m)
+    if (!(ell_j[m] > 0.0)) { h->err = "rcgp_sobol_cross: lengthscales must be positive"; return -2; }
+  int rc;
+  if ((rc = rcgp_factor(h))) return rc;
+  return rc_sobol(h, ell_j, var_j, alpha_j, n_slices, slices, V);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------------------------------------------------
+int rc_prof_collect(rcgp_handle_s* h) {
+  RC_HIP(hipStreamSynchronize(h->stream));
+  for (auto& ev : h->prof_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) {
+      h->prof_ms[ev.cls] += (double)ms;
+      h->prof_count[ev.cls] += 1;
+    }
+    (void)hipEventDestroy(ev.start);
+    (void)hipEventDestroy(ev.stop);
+  }
+  h->prof_events.clear();
+  return 0;
+}
+
+RC_API int rcgp_set_profiling(rcgp_handle h, int on) {
+  RC_CHECK_H(h);
+  int rc = rc_prof_collect(h);
+  h->profiling = (on != 0);
+  return rc;
+}
+
+RC_API int rcgp_profile_reset(rcgp_handle h) {
+  RC_CHECK_H(h);
+  int rc = rc_prof_collect(h);
+  for (int c = 0; c < RC_K_COUNT; ++c) { h->prof_ms[c] = 0.0; h->prof_count[c] = 0; h->prof_work[c] = 0.0; }
+  return rc;
+}
+
+RC_API int rcgp_profile_get(rcgp_handle h, int cls, int64_t* launches, double* total_ms, double* work) {
+  RC_CHECK_H(h);
+  if (cls < 0 || cls >= RC_K_COUNT) return -2;
+  int rc = rc_prof_collect(h);
+  if (launches) *launches = (int64_t)h->prof_count[cls];
+  if (total_ms) *total_ms = h->prof_ms[cls];
+  if (work) *work = h->prof_work[cls];
+  return rc;
+}

@@ -1,0 +1,133 @@
+// Shared declarations for librcgp (gfx950 only): handle layout, error macros, launch prototypes.
+// The public C ABI is include/rcgp.h; nothing here is exported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#define RC_TILE 128            // edge of a workgroup tile and of a diagonal Cholesky block
+#define RC_BK 16               // k-depth of one LDS stage of the MFMA GEMM
+#define RC_MAX_M 64            // largest input dimensionality supported by the fused kernels
+#define RC_NB_OUTER 512        // outer panel width of the blocked Cholesky (K of the trailing update)
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// Profiled kernel classes (rcgp_profile_get). Order is part of the ABI (include/rcgp.h).
+enum RcKernelClass {
+  RC_K_GRAM = 0,       // Gram build
+  RC_K_GEMM = 1,       // fp64 MFMA GEMM family (trailing update, trsm, trtri, K^-1/gradient, predict)
+  RC_K_DIAG = 2,       // 128x128 diagonal-block potrf + inverse
+  RC_K_SOBOL = 3,      // Sobol pair kernel
+  RC_K_MISC = 4,       // reductions, gemv, prep
+  RC_K_COUNT = 5
+};
+
+struct RcProfEvent { hipEvent_t start, stop; int cls; };
+
+struct rcgp_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t N = 0, Np = 0;       // rows, rows padded to a multiple of RC_TILE
+  int M = 0;
+  // hyper-parameters (constrained space)
+  std::vector<double> ell;
+  double var = 1.0, noise = 0.0;
+  bool hyper_set = false;
+  // state flags
+  bool factored = false;       // A holds L (lower), w = L^-1 y, logdiag valid
+  bool inverted = false;       // Linv holds L^-1, alpha valid
+  // device buffers
+  double *X = nullptr;         // Np x M (padded rows are 0)
+  double *Z = nullptr;         // Np x M, X / ell
+  double *sq = nullptr;        // Np, -0.5 |z_i|^2
+  double *y = nullptr;         // Np (padded 0): pristine targets
+  double *w = nullptr;         // Np: running rhs during potrf, then L^-1 y
+  double *alpha = nullptr;     // Np: K^-1 y
+  double *A = nullptr;         // Np x Np: Gram, then L in the lower triangle
+  double *Linv = nullptr;      // Np x Np: L^-1 (allocated on first use)
+  double *S = nullptr;         // Np x Np scratch (trtri temporaries, predict) (allocated on first use)
+  double *invdiag = nullptr;   // (Np/128) x 128 x 128 inverses of the diagonal blocks of L
+  double *logdiag = nullptr;   // Np: log L_ii
+  double *partial = nullptr;   // scratch for two-stage reductions
+  size_t partial_elems = 0;
+  double *scal = nullptr;      // small device scalars/vectors for results
+  int *info = nullptr;         // device: 0 ok, k>0 = leading minor k not positive definite
+  double *ell_d = nullptr;     // device copy of ell (M)
+  // predict scratch
+  double *Xs = nullptr, *Zs = nullptr, *sqs = nullptr, *KsT = nullptr, *pmean = nullptr, *pvar = nullptr;
+  int64_t pred_cap = 0;
+  // sobol scratch
+  double *sob = nullptr;       // prep arrays
+  size_t sob_elems = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<RcProfEvent> prof_events;
+  double prof_ms[RC_K_COUNT] = {0, 0, 0, 0, 0};
+  long prof_count[RC_K_COUNT] = {0, 0, 0, 0, 0};
+  double prof_work[RC_K_COUNT] = {0, 0, 0, 0, 0};   // algorithmic flops (GEMM) or bytes (Gram) or pair-terms (Sobol)
+  std::string err;
+};
+
+#define RC_HIP(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      return -100 - (int)e_;                                                               \
+    }                                                                                      \
+  } while (0)
+
+// RAII-less profiling bracket: records events around one kernel launch when profiling is on.
+struct RcProfScope {
+  rcgp_handle_s* h; int idx;
+  RcProfScope(rcgp_handle_s* h_, int cls, double work) : h(h_), idx(-1) {
+    if (!h->profiling) return;
+    RcProfEvent ev; ev.cls = cls;
+    if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) return;
+    (void)hipEventRecord(ev.start, h->stream);
+    h->prof_events.push_back(ev);
+    idx = (int)h->prof_events.size() - 1;
+    h->prof_work[cls] += work;
+  }
+  ~RcProfScope() { if (idx >= 0) (void)hipEventRecord(h->prof_events[idx].stop, h->stream); }
+};
+
+// ---- gram.hip
+int rc_launch_scale(rcgp_handle_s* h);                       // Z = X/ell, sq = -0.5|z|^2
+int rc_launch_scale_rows(rcgp_handle_s* h, const double* X, double* Z, double* sq, int64_t rows);
+int rc_launch_gram(rcgp_handle_s* h);                        // A lower tiles = var*exp(.) (+noise on diag; identity on padding)
+int rc_launch_cross_gram(rcgp_handle_s* h, int64_t n, int64_t np);   // KsT (np x Np) from Zs, Z
+
+// ---- gemm.hip (all matrices row-major, dims multiples of 128)
+// C[i][j] -= sum_k P[i][k] P[j][k]   lower tiles of an n x n matrix, K = kk
+int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk);
+// C (m x n) -= Arows (m x kk) * Brows (n x kk)^T ; tiles strictly above the diagonal of C (given the global row/col offsets) skipped
+int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
+                          int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0);
+// panel trsm: P (m x 128) <- P * invL^T ; rhs (m) -= P_new * wj (128)
+int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double* invL, int64_t m, double* rhs, const double* wj);
+// trtri level: for each pair p at block size s. T = B * Ainv (lower-tri Ainv); X21 = -Cinv * T
+int rc_launch_trtri_level(rcgp_handle_s* h, int64_t s);
+// K^-1 tiles fused with the LML-gradient reduction; partial sums -> h->partial ; returns number of partial rows via *nrows
+int rc_launch_grad(rcgp_handle_s* h, int* nrows);
+// predict: colsum((Linv * Ks)^2) for np test points -> h->pvar (np)
+int rc_launch_predict_var(rcgp_handle_s* h, int64_t np);
+
+// ---- potrf.hip
+int rc_potrf(rcgp_handle_s* h);                              // blocked Cholesky of A in place, w = L^-1 y, logdiag
+int rc_launch_diag(rcgp_handle_s* h, int64_t j);             // factor + invert diagonal block j (row/col offset), w_j
+
+// ---- solve.hip
+int rc_trtri(rcgp_handle_s* h);                              // Linv = L^-1
+int rc_alpha(rcgp_handle_s* h);                              // alpha = Linv^T w
+int rc_lml_value(rcgp_handle_s* h, double* lml);             // from logdiag and w
+int rc_grad_finish(rcgp_handle_s* h, int nrows, double* grad);
+
+// ---- sobol.hip
+int rc_sobol(rcgp_handle_s* h, const double* ell_j, double var_j, const double* alpha_j_host, int n_slices, const int32_t* slices,
+             double* V_host);
+
+// ---- util
+int rc_ensure_partial(rcgp_handle_s* h, size_t elems);
+int rc_prof_collect(rcgp_handle_s* h);

@@ -1,0 +1,337 @@
+// Closed-form Sobol conditional variances V_lj(S) = sum_{n,n'} g_l[n] g_j[n'] prod_{m in S} h_m(n,n') for independent GPs.
+// Restates gsa.calibrators.ClosedSobol._calibrate/_V/marginalize (gsa/calibrators.py:49-97) and the gsa.base.Gaussian
+// arithmetic they call (gsa/base.py:92-126), reduced algebraically (DESIGN.md, section "Sobol algebra") to
+//   log h_m(n,n') = c0_m + pl_m x_nm^2 + pj_m x_n'm^2 + c2_m x_nm x_n'm
+//   a_m = phi_l,m phi_j,m ; c0 = -1/2 log(1-a) ; c2 = a/(1-a) ; pl = -1/2 c2 phi_l ; pj = -1/2 c2 phi_j ; phi = 1/(ell^2+1).
+// The reference materialises (N,N,M) tensors per slice; here one pass over 128x128 pair tiles serves all first-order
+// [m,m+1), closed [0,m+1) and total-complement [m+1,M) slices (gsa/models.py:77-90) with running sums in registers.
+// VALU-bound (fp64 exp), traffic ~ 2 N M doubles per tile from L2: no HBM roofline applies.
+#include "common.h"
+#include "rc_math.h"
+
+#define XST 130
+
+// graw[i] = pre * exp(-1/2 sum_m phi_m x_im^2) * alpha_i   (gsa/calibrators.py:86-89); padded rows -> 0
+__global__ void k_sobol_g0(const double* __restrict__ X, const double* __restrict__ alpha, const double* __restrict__ phi, double pre,
+                           int64_t N, int64_t Np, int M, double* __restrict__ g) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Np) return;
+  double v = 0.0;
+  if (i < N) {
+    double s = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const double x = X[i * M + m];
+      s = fma(phi[m] * x, x, s);
+    }
+    v = pre * rc_exp(-0.5 * s) * alpha[i];
+  }
+  g[i] = v;
+}
+
+__global__ void __launch_bounds__(1024) k_sum1(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
+  __shared__ double sm[1024];
+  double a = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) a += v[i];
+  sm[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+// g -= mean (over the N valid rows, gsa/calibrators.py:90); out_sum[1] = sum of centred g (for the empty slice)
+__global__ void k_sobol_center(double* __restrict__ g, int64_t N, const double* __restrict__ sum) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) g[i] -= sum[0] / (double)N;
+}
+
+// Pair-tile kernel. consts = [c0 | c2 | pl | pj] (4 x M). Output partial[blk][3*M]: first[m], closed[m], total[m] where
+// total[m] is the slice [m+1, M) (total[M-1] = empty slice, left 0 here and filled by the caller).
+// mode 0: canonical (all three kinds). mode 1: one arbitrary slice [ma, mb), result in column 0.
+template <bool SYM>
+__global__ void __launch_bounds__(256) k_sobol_pairs(const double* __restrict__ X, const double* __restrict__ gl,
+                                                     const double* __restrict__ gj, const double* __restrict__ consts, int M, int mode,
+                                                     int ma, int mb, double* __restrict__ partial) {
+  extern __shared__ double sm[];
+  double* xi = sm;                     // [M][XST]
+  double* xj = sm + M * XST;           // [M][XST]
+  double* wsum = xj + M * XST;         // [4][3*M]
+  int ti, tj;
+  if (SYM) {
+    int t = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((int64_t)(t + 1) * (t + 2) / 2 <= (int64_t)blockIdx.x) ++t;
+    while ((int64_t)t * (t + 1) / 2 > (int64_t)blockIdx.x) --t;
+    ti = t;
+    tj = (int)(blockIdx.x - (int64_t)t * (t + 1) / 2);
+  } else {
+    tj = blockIdx.x;
+    ti = blockIdx.y;
+  }
+  const int64_t blk = SYM ? (int64_t)blockIdx.x : (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int e = t; e < 128 * M; e += 256) {
+    const int rr = e / M, m = e - rr * M;
+    xi[m * XST + rr] = X[((int64_t)ti * 128 + rr) * M + m];
+    xj[m * XST + rr] = X[((int64_t)tj * 128 + rr) * M + m];
+  }
+  for (int e = t; e < 4 * 3 * M; e += 256) wsum[e] = 0.0;
+  const int tx = t & 15, ty = t >> 4;
+  double gi[8], gc[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) gi[a] = gl[(int64_t)ti * 128 + ty + 16 * a];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    gc[2 * b] = gj[(int64_t)tj * 128 + 2 * tx + 32 * b];
+    gc[2 * b + 1] = gj[(int64_t)tj * 128 + 2 * tx + 32 * b + 1];
+  }
+  __syncthreads();
+  const double* c0 = consts;
+  const double* c2 = consts + M;
+  const double* pl = consts + 2 * M;
+  const double* pj = consts + 3 * M;
+  auto wave_sum = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  double e[8][8];
+  // ---------------- ascending pass: first-order and closed (or the single generic slice)
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) e[a][c] = 0.0;
+  const int m_lo = (mode == 0) ? 0 : ma, m_hi = (mode == 0) ? M : mb;
+  for (int m = m_lo; m < m_hi; ++m) {
+    const double k0 = c0[m], k2 = c2[m], kl = pl[m], kj = pj[m];
+    double ai[8], ui[8], bj[8], xc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const double x = xi[m * XST + ty + 16 * a];
+      ai[a] = fma(kl * x, x, k0);
+      ui[a] = k2 * x;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const double2 x = *reinterpret_cast<const double2*>(xj + m * XST + 2 * tx + 32 * b);
+      xc[2 * b] = x.x;
+      xc[2 * b + 1] = x.y;
+      bj[2 * b] = kj * x.x * x.x;
+      bj[2 * b + 1] = kj * x.y * x.y;
+    }
+    double sf = 0.0, sc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      double rf = 0.0, rc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const double tm = fma(ui[a], xc[c], ai[a] + bj[c]);
+        e[a][c] += tm;
+        if (mode == 0) {
+          rf = fma(gc[c], rc_exp(tm), rf);
+          rc = fma(gc[c], rc_exp(e[a][c]), rc);
+        }
+      }
+      sf = fma(gi[a], rf, sf);
+      sc = fma(gi[a], rc, sc);
+    }
+    if (mode == 0) {
+      sf = wave_sum(sf);
+      sc = wave_sum(sc);
+      if (lane == 0) {
+        wsum[wave * 3 * M + m] = sf;
+        wsum[wave * 3 * M + M + m] = sc;
+      }
+    }
+  }
+  if (mode != 0) {
+    double sc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      double rc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) rc = fma(gc[c], rc_exp(e[a][c]), rc);
+      sc = fma(gi[a], rc, sc);
+    }
+    sc = wave_sum(sc);
+    if (lane == 0) wsum[wave * 3 * M] = sc;
+  } else {
+    // ---------------- descending pass: complements [m, M) for m = M-1 .. 1  -> total[m-1]
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) e[a][c] = 0.0;
+    for (int m = M - 1; m >= 1; --m) {
+      const double k0 = c0[m], k2 = c2[m], kl = pl[m], kj = pj[m];
+      double ai[8], ui[8], bj[8], xc[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const double x = xi[m * XST + ty + 16 * a];
+        ai[a] = fma(kl * x, x, k0);
+        ui[a] = k2 * x;
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const double2 x = *reinterpret_cast<const double2*>(xj + m * XST + 2 * tx + 32 * b);
+        xc[2 * b] = x.x;
+        xc[2 * b + 1] = x.y;
+        bj[2 * b] = kj * x.x * x.x;
+        bj[2 * b + 1] = kj * x.y * x.y;
+      }
+      double st = 0.0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        double rt = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          e[a][c] += fma(ui[a], xc[c], ai[a] + bj[c]);
+          rt = fma(gc[c], rc_exp(e[a][c]), rt);
+        }
+        st = fma(gi[a], rt, st);
+      }
+      st = wave_sum(st);
+      if (lane == 0) wsum[wave * 3 * M + 2 * M + (m - 1)] = st;
+    }
+  }
+  __syncthreads();
+  const double wgt = (SYM && ti != tj) ? 2.0 : 1.0;
+  for (int c = t; c < 3 * M; c += 256)
+    partial[blk * 3 * M + c] = wgt * ((wsum[c] + wsum[3 * M + c]) + (wsum[2 * 3 * M + c] + wsum[3 * 3 * M + c]));
+}
+
+__global__ void __launch_bounds__(256) k_rowreduce_s(const double* __restrict__ partial, int64_t rows, int cols, double* __restrict__ out) {
+  __shared__ double sm[256];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int64_t r = threadIdx.x; r < rows; r += 256) s += partial[r * cols + c];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = sm[0];
+}
+
+static int sobol_make_g(rcgp_handle_s* h, const double* ell, double var, const double* alpha_d, double* phi_d, double* g_d,
+                        double* sum_d, std::vector<double>& phi_host) {
+  const int M = h->M;
+  phi_host.resize(M);
+  double pre = var;
+  for (int m = 0; m < M; ++m) {
+    const double l2 = ell[m] * ell[m];
+    phi_host[m] = 1.0 / (l2 + 1.0);
+    pre *= sqrt(l2 * phi_host[m]);                        // sqrt(prod ell^2/(ell^2+1)) * F  (gsa/calibrators.py:86)
+  }
+  RC_HIP(hipMemcpyAsync(phi_d, phi_host.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));               // phi_host may be reused by the caller
+  RcProfScope ps(h, RC_K_MISC, 0.0);
+  const unsigned nb = (unsigned)((h->Np + 255) / 256);
+  hipLaunchKernelGGL(k_sobol_g0, dim3(nb), dim3(256), 0, h->stream, h->X, alpha_d, phi_d, pre, h->N, h->Np, M, g_d);
+  hipLaunchKernelGGL(k_sum1, dim3(1), dim3(1024), 0, h->stream, g_d, h->N, sum_d);
+  hipLaunchKernelGGL(k_sobol_center, dim3(nb), dim3(256), 0, h->stream, g_d, h->N, sum_d);
+  hipLaunchKernelGGL(k_sum1, dim3(1), dim3(1024), 0, h->stream, g_d, h->N, sum_d + 1);
+  RC_HIP(hipGetLastError());
+  return 0;
+}
+
+int rc_sobol(rcgp_handle_s* h, const double* ell_j, double var_j, const double* alpha_j_host, int n_slices, const int32_t* slices,
+             double* V_host) {
+  const int M = h->M;
+  const int64_t Np = h->Np, T = Np / 128;
+  const bool sym = (ell_j == nullptr);
+  // scratch layout in h->sob: g_l[Np] g_j[Np] alpha_j[Np] phi_l[M] phi_j[M] consts[4M] sums[4] out[3M]
+  const size_t need = (size_t)3 * Np + 2 * M + 4 * M + 4 + 3 * M;
+  if (h->sob_elems < need) {
+    if (h->sob) { RC_HIP(hipStreamSynchronize(h->stream)); RC_HIP(hipFree(h->sob)); h->sob = nullptr; }
+    RC_HIP(hipMalloc(&h->sob, need * sizeof(double)));
+    h->sob_elems = need;
+  }
+  double* g_l = h->sob;
+  double* g_j = g_l + Np;
+  double* a_j = g_j + Np;
+  double* phi_l_d = a_j + Np;
+  double* phi_j_d = phi_l_d + M;
+  double* consts_d = phi_j_d + M;
+  double* sums_d = consts_d + 4 * M;
+  double* out_d = sums_d + 4;
+  std::vector<double> phi_l, phi_j;
+  int rc = sobol_make_g(h, h->ell.data(), h->var, h->alpha, phi_l_d, g_l, sums_d, phi_l);
+  if (rc) return rc;
+  if (!sym) {
+    RC_HIP(hipMemsetAsync(a_j, 0, (size_t)Np * sizeof(double), h->stream));
+    RC_HIP(hipMemcpyAsync(a_j, alpha_j_host, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = sobol_make_g(h, ell_j, var_j, a_j, phi_j_d, g_j, sums_d + 2, phi_j);
+    if (rc) return rc;
+  } else {
+    phi_j = phi_l;
+    g_j = g_l;
+  }
+  std::vector<double> consts(4 * M);
+  for (int m = 0; m < M; ++m) {
+    const double a = phi_l[m] * phi_j[m];
+    consts[m] = -0.5 * log1p(-a);
+    consts[M + m] = a / (1.0 - a);
+    consts[2 * M + m] = -0.5 * consts[M + m] * phi_l[m];
+    consts[3 * M + m] = -0.5 * consts[M + m] * phi_j[m];
+  }
+  RC_HIP(hipMemcpyAsync(consts_d, consts.data(), (size_t)4 * M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  double sums[4];
+  RC_HIP(hipMemcpy(sums, sums_d, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  const double empty_value = sym ? sums[1] * sums[1] : sums[1] * sums[3];
+
+  const int64_t nblk = sym ? T * (T + 1) / 2 : T * T;
+  rc = rc_ensure_partial(h, (size_t)nblk * 3 * M);
+  if (rc) return rc;
+  const size_t lds = (size_t)(2 * M * XST + 4 * 3 * M) * sizeof(double);
+  RC_HIP(hipFuncSetAttribute((const void*)k_sobol_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RC_HIP(hipFuncSetAttribute((const void*)k_sobol_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const double pairs = sym ? (double)h->N * ((double)h->N + 1.0) / 2.0 : (double)h->N * (double)h->N;
+
+  auto run = [&](int mode, int ma, int mb, std::vector<double>& out) -> int {
+    {
+      RcProfScope ps(h, RC_K_SOBOL, pairs * (mode == 0 ? (double)(3 * M - 1) : 1.0));     // exp evaluations
+      if (sym)
+        hipLaunchKernelGGL(k_sobol_pairs<true>, dim3((unsigned)nblk), dim3(256), lds, h->stream, h->X, g_l, g_j, consts_d, M, mode, ma, mb,
+                           h->partial);
+      else
+        hipLaunchKernelGGL(k_sobol_pairs<false>, dim3((unsigned)T, (unsigned)T), dim3(256), lds, h->stream, h->X, g_l, g_j, consts_d, M,
+                           mode, ma, mb, h->partial);
+      RC_HIP(hipGetLastError());
+    }
+    {
+      RcProfScope ps(h, RC_K_MISC, 0.0);
+      hipLaunchKernelGGL(k_rowreduce_s, dim3((unsigned)(3 * M)), dim3(256), 0, h->stream, h->partial, nblk, 3 * M, out_d);
+      RC_HIP(hipGetLastError());
+    }
+    out.resize(3 * M);
+    RC_HIP(hipMemcpyAsync(out.data(), out_d, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RC_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+  };
+
+  std::vector<double> canon;
+  bool have_canon = false;
+  for (int s = 0; s < n_slices; ++s) {
+    const int a = slices[2 * s], b = slices[2 * s + 1];
+    if (a < 0 || b > M || a > b) { h->err = "sobol: bad slice"; return -2; }
+    if (a == b) { V_host[s] = empty_value; continue; }
+    const bool canonical = (b == a + 1) || (a == 0) || (b == M);
+    if (canonical) {
+      if (!have_canon) {
+        if ((rc = run(0, 0, M, canon))) return rc;
+        have_canon = true;
+      }
+      if (a == 0) V_host[s] = canon[M + (b - 1)];              // closed [0,b)
+      else if (b == M) V_host[s] = canon[2 * M + (a - 1)];      // complement [a,M)
+      else V_host[s] = canon[a];                                // first-order [a,a+1)
+    } else {
+      std::vector<double> one;
+      if ((rc = run(1, a, b, one))) return rc;
+      V_host[s] = one[0];
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,146 @@
+// Everything between the Cholesky factor and the numbers the host wants: L^-1 (recursive doubling on the MFMA GEMM),
+// alpha = K^-1 y, the LML value, and the final reduction of the fused gradient partials.
+// Reference call sites: GPflow multivariate_normal / cholesky_solve at gpr/models.py:360-370, 441-444.
+#include "common.h"
+
+int rc_ensure_partial(rcgp_handle_s* h, size_t elems) {
+  if (h->partial_elems >= elems) return 0;
+  if (h->partial) { RC_HIP(hipStreamSynchronize(h->stream)); RC_HIP(hipFree(h->partial)); h->partial = nullptr; }
+  RC_HIP(hipMalloc(&h->partial, elems * sizeof(double)));
+  h->partial_elems = elems;
+  return 0;
+}
+
+__global__ void k_put_diag(double* __restrict__ W, int64_t ld, const double* __restrict__ invdiag) {
+  const int64_t b = blockIdx.x;
+  double* Wt = W + b * 128 * ld + b * 128;
+  const double* src = invdiag + b * 128 * 128;
+  for (int e = threadIdx.x; e < 128 * 128; e += blockDim.x) Wt[(int64_t)(e >> 7) * ld + (e & 127)] = src[e];
+}
+
+int rc_trtri(rcgp_handle_s* h) {
+  const int64_t Np = h->Np;
+  if (!h->Linv) RC_HIP(hipMalloc(&h->Linv, (size_t)Np * Np * sizeof(double)));
+  if (!h->S) RC_HIP(hipMalloc(&h->S, (size_t)Np * Np * sizeof(double)));
+  {
+    RcProfScope ps(h, RC_K_MISC, 0.0);
+    hipLaunchKernelGGL(k_put_diag, dim3((unsigned)(Np / 128)), dim3(256), 0, h->stream, h->Linv, Np, h->invdiag);
+    RC_HIP(hipGetLastError());
+  }
+  for (int64_t s = 128; s < Np; s *= 2) {
+    int rc = rc_launch_trtri_level(h, s);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// partial[kc][j] = sum_{k in chunk kc, k >= tile start of j} Linv[k][j] * w[k]   (rows above the diagonal tile are never read)
+__global__ void __launch_bounds__(256) k_gemvT_partial(const double* __restrict__ Linv, int64_t ld, const double* __restrict__ w,
+                                                       int64_t Np, int rows_per_chunk, double* __restrict__ partial) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t k0c = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t k1 = (k0c + rows_per_chunk < Np) ? k0c + rows_per_chunk : Np;
+  double s = 0.0;
+  if (j < Np) {
+    int64_t k0 = (j >> 7) << 7;
+    if (k0 < k0c) k0 = k0c;
+    for (int64_t k = k0; k < k1; ++k) s = fma(Linv[k * ld + j], w[k], s);
+    partial[(int64_t)blockIdx.y * Np + j] = s;
+  }
+}
+
+__global__ void k_colreduce2(const double* __restrict__ partial, int64_t rows, int64_t n, double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s = 0.0;
+  for (int64_t r = 0; r < rows; ++r) s += partial[r * n + j];
+  out[j] = s;
+}
+
+int rc_alpha(rcgp_handle_s* h) {
+  const int64_t Np = h->Np;
+  const int rows_per_chunk = 512;
+  const int64_t chunks = (Np + rows_per_chunk - 1) / rows_per_chunk;
+  int rc = rc_ensure_partial(h, (size_t)chunks * Np);
+  if (rc) return rc;
+  RcProfScope ps(h, RC_K_MISC, 0.0);
+  hipLaunchKernelGGL(k_gemvT_partial, dim3((unsigned)((Np + 255) / 256), (unsigned)chunks), dim3(256), 0, h->stream, h->Linv, Np, h->w, Np,
+                     rows_per_chunk, h->partial);
+  RC_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_colreduce2, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, h->stream, h->partial, chunks, Np, h->alpha);
+  RC_HIP(hipGetLastError());
+  return 0;
+}
+
+// Deterministic single-block reductions: out[0] = sum w^2, out[1] = sum logdiag.
+__global__ void __launch_bounds__(1024) k_lml_reduce(const double* __restrict__ w, const double* __restrict__ logdiag, int64_t n,
+                                                     double* __restrict__ out) {
+  __shared__ double sa[1024], sb[1024];
+  double a = 0.0, b = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    a = fma(w[i], w[i], a);
+    b += logdiag[i];
+  }
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sa[threadIdx.x] += sa[threadIdx.x + o];
+      sb[threadIdx.x] += sb[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = sa[0]; out[1] = sb[0]; }
+}
+
+int rc_lml_value(rcgp_handle_s* h, double* lml) {
+  {
+    RcProfScope ps(h, RC_K_MISC, 0.0);
+    hipLaunchKernelGGL(k_lml_reduce, dim3(1), dim3(1024), 0, h->stream, h->w, h->logdiag, h->Np, h->scal);
+    RC_HIP(hipGetLastError());
+  }
+  double host[2];
+  int info = 0;
+  RC_HIP(hipMemcpyAsync(host, h->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  if (info != 0) {
+    h->err = "matrix is not positive definite: leading minor " + std::to_string(info);
+    h->factored = false;
+    return info;
+  }
+  *lml = -0.5 * host[0] - host[1] - 0.5 * (double)h->N * 1.8378770664093454836;   // log(2 pi)
+  return 0;
+}
+
+// out[c] = sum_r partial[r][c], one block per column, fixed-order tree.
+__global__ void __launch_bounds__(256) k_rowreduce(const double* __restrict__ partial, int64_t rows, int cols, double* __restrict__ out) {
+  __shared__ double sm[256];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int64_t r = threadIdx.x; r < rows; r += 256) s += partial[r * cols + c];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = sm[0];
+}
+
+int rc_grad_finish(rcgp_handle_s* h, int nrows, double* grad) {
+  const int M = h->M;
+  {
+    RcProfScope ps(h, RC_K_MISC, 0.0);
+    hipLaunchKernelGGL(k_rowreduce, dim3((unsigned)(M + 2)), dim3(256), 0, h->stream, h->partial, (int64_t)nrows, M + 2, h->scal + 8);
+    RC_HIP(hipGetLastError());
+  }
+  std::vector<double> host(M + 2);
+  RC_HIP(hipMemcpyAsync(host.data(), h->scal + 8, (size_t)(M + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  for (int m = 0; m < M; ++m) grad[m] = 0.5 * host[m] / h->ell[m];     // dK/dell_m = K (z_im - z_jm)^2 / ell_m
+  grad[M] = 0.5 * host[M] / h->var;
+  grad[M + 1] = 0.5 * host[M + 1];
+  return 0;
+}
