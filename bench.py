@@ -1,0 +1,160 @@
+"""Headline benchmark (BASELINE.json): GP fit + closed-form Sobol wall-time and train-points/s, fp64, one fold per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the hot path over one synthetic fold resident in HBM: L-BFGS-B hyper-parameter fit from the
+reference's default start (ell 5.0, variance 2.0, noise 0.02; gpr/kernels.py:49-50, gpr/models.py:52) with the reference's
+optimiser options (maxiter 5000, gtol 1e-16; gpr/models.py:327-330) to convergence, then the closed-form first-order /
+closed / total Sobol indices (3M+1 quadratic forms), then the gather of every rank's indices (RCCL when N > 1).
+Weak scaling: rank r owns fold k = r (its own N x M design); value = ranks * N * steps / max-over-ranks wall time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (AMD spec). Sustained micro-benchmark: DESIGN.md.
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def all_slices(M):
+    first = [(m, m + 1) for m in range(M)]
+    closed = [(0, m + 1) for m in range(M)]
+    complement = [(m + 1, M) for m in range(M)]
+    return first + closed + complement + [(0, M)]
+
+
+def sobol_indices(V, M):
+    """First-order, closed and total indices from the 3M+1 conditional variances (gsa/models.py:207-214)."""
+    full = V[3 * M]
+    return np.concatenate([V[:M] / full, V[M:2 * M] / full, 1.0 - V[2 * M:3 * M] / full])
+
+
+def cpu_baseline(N, M, nfev):
+    """The oracle timed on this box's host cores on a bounded sample, scaled to the workload (N^3 for an LML+gradient
+    evaluation, N^2 for the Sobol quadratic forms)."""
+    from oracle import gp_oracle as o
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    ne, ns = min(N, 4096), min(N, 2048)
+    X, y = o.synthetic_fold(ne, M)
+    ell, var, noise = o.bench_hyper(M)
+    t0 = time.perf_counter()
+    o.lml_and_grad(X, y, ell, var, 1e-2)
+    te = time.perf_counter() - t0
+    Xs, ys = o.synthetic_fold(ns, M)
+    alpha = o.k_inv_y(Xs, ys, ell, var, 1e-2)
+    g, phi = o.sobol_prepare(Xs, alpha[None, :], np.array([var]), ell[None, :])
+    t0 = time.perf_counter()
+    o.sobol_V_pair(Xs, g[0], g[0], phi[0], phi[0], o.all_slices(M))
+    ts = time.perf_counter() - t0
+    t_full = nfev * te * (N / ne) ** 3 + ts * (N / ns) ** 2
+    return {'value': N / t_full, 'unit': 'train-points/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'oracle (NumPy/SciPy fp64): 1 LML+gradient evaluation at N={ne} ({te:.2f} s) scaled by (N/{ne})^3 x {nfev} '
+                      f'evaluations + {3 * M + 1} Sobol quadratic forms at N={ns} ({ts:.2f} s) scaled by (N/{ns})^2; '
+                      f'estimated fit+Sobol wall time {t_full:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--n', type=int, default=16384, help='training rows per fold (BASELINE configs[2]: 16384)')
+    ap.add_argument('--m', type=int, default=10, help='input dimensions (BASELINE configs[2]: 10)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from romcomma_amd import _lib, dist
+    from romcomma_amd.gpr.optimize import fit_lbfgsb
+    from romcomma_amd.user.sample import synthetic_fold
+
+    rank, world, local_rank = dist.env_rank_world()
+    if world > 1:
+        dist.init_process_group()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    if _lib.device_count() <= 0:
+        raise SystemExit('bench.py needs a GPU: librcgp has no CPU fallback')
+
+    N, M = args.n, args.m
+    X, y = synthetic_fold(N, M, k=rank)
+    gp = _lib.RcGP(X, y, device=local_rank)         # inputs resident in HBM from here on
+    slices = all_slices(M)
+    last = {}
+
+    def step():
+        fit = fit_lbfgsb(gp, 5.0 * np.ones(M), 2.0, 0.02)
+        V = gp.sobol_closed(slices)
+        row = np.concatenate([sobol_indices(V, M), fit['lengthscales'], [fit['variance'], fit['noise'], fit['log_marginal'], fit['nfev']]])
+        table = dist.all_gather_rows(row[None, :], world, [rank])      # the one collective: every rank's indices
+        last.update(fit=fit, V=V, table=table)
+
+    for _ in range(args.warmup):
+        step()
+    gp.set_profiling(True)
+    gp.profile_reset()
+    gp.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    gp.sync()
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    prof = {name: gp.profile_get(c) for c, name in enumerate(_lib.KERNEL_CLASS_NAMES)}
+    gp.set_profiling(False)
+
+    if rank == 0:
+        n_gemm, ms_gemm, flops = prof['gemm']
+        n_gram, ms_gram, gram_bytes = prof['gram']
+        n_sob, ms_sob, sob_exps = prof['sobol']
+        n_diag, ms_diag, _ = prof['diag']
+        achieved = flops / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
+        nfev = int(last['fit']['nfev'])
+        out = {
+            'metric': 'GP-fit+Sobol train-points/s (wall-time per fit+Sobol in ms_per_step), fp64',
+            'value': world * N * args.steps / elapsed,
+            'unit': 'train-points/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'C2: ARD-RBF GP fit (L-BFGS-B to convergence, reference defaults) + closed-form Sobol first/closed/'
+                                   f'total indices, N={N}, M={M}, L=1, one fold per GPU',
+                       'N': N, 'M': M, 'lbfgs_evaluations_last_step': nfev, 'parallelism': f'fold-per-gpu x{world}',
+                       'log_marginal': last['fit']['log_marginal']},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'kernel': 'fp64 MFMA GEMM family (Cholesky trailing update/trsm, L^-1, fused K^-1+gradient)',
+                         'launches': int(n_gemm), 'avg_launch_ms': ms_gemm / max(n_gemm, 1),
+                         'algorithmic_flops_per_launch': flops / max(n_gemm, 1)},
+            'stages': {
+                'gram': {'bound': 'hbm', 'achieved_GBs': gram_bytes / (ms_gram * 1e-3) / 1e9 if ms_gram > 0 else 0.0, 'peak_GBs': HBM_PEAK_GBS,
+                         'frac': (gram_bytes / (ms_gram * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_gram > 0 else 0.0,
+                         'launches': int(n_gram), 'avg_launch_ms': ms_gram / max(n_gram, 1)},
+                'diag_blocks': {'launches': int(n_diag), 'total_ms': ms_diag},
+                'sobol': {'launches': int(n_sob), 'total_ms': ms_sob, 'Gexp_per_s': sob_exps / (ms_sob * 1e-3) / 1e9 if ms_sob > 0 else 0.0},
+                'gemm_total_ms': ms_gemm, 'timed_region_ms': 1e3 * elapsed},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(N, M, nfev)
+        print(json.dumps(out), flush=True)
+    gp.close()
+    if world > 1:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -25,8 +25,10 @@ static void free_all(rcgp_handle_s* h) {
   for (auto b : bufs)
     if (*b) { hipFree(*b); *b = nullptr; }
   if (h->info) { hipFree(h->info); h->info = nullptr; }
-  for (auto& ev : h->prof_events) { hipEventDestroy(ev.start); hipEventDestroy(ev.stop); }
+  for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
   h->prof_events.clear();
+  for (auto& e : h->event_pool) (void)hipEventDestroy(e);
+  h->event_pool.clear();
   if (h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
 }
 
@@ -193,9 +195,9 @@ RC_API int rcgp_lml_grad(rcgp_handle h, double* lml, double* grad) {
   if (!lml || !grad) return -2;
   int rc;
   if ((rc = ensure_factor(h, true))) return rc;
-  if ((rc = rc_lml_value(h, lml))) return rc;
   int nrows = 0;
-  if ((rc = rc_launch_grad(h, &nrows))) return rc;
+  if ((rc = rc_launch_grad(h, &nrows))) return rc;          // queued behind the factorisation: one host sync per evaluation
+  if ((rc = rc_lml_value(h, lml))) return rc;
   return rc_grad_finish(h, nrows, grad);
 }
 
@@ -337,8 +339,8 @@ int rc_prof_collect(rcgp_handle_s* h) {
       h->prof_ms[ev.cls] += (double)ms;
       h->prof_count[ev.cls] += 1;
     }
-    (void)hipEventDestroy(ev.start);
-    (void)hipEventDestroy(ev.stop);
+    h->event_pool.push_back(ev.start);
+    h->event_pool.push_back(ev.stop);
   }
   h->prof_events.clear();
   return 0;

@@ -63,6 +63,7 @@ struct rcgp_handle_s {
   // profiling
   bool profiling = false;
   std::vector<RcProfEvent> prof_events;
+  std::vector<hipEvent_t> event_pool;     // recycled events (no create/destroy on the launch path after warm-up)
   double prof_ms[RC_K_COUNT] = {0, 0, 0, 0, 0};
   long prof_count[RC_K_COUNT] = {0, 0, 0, 0, 0};
   double prof_work[RC_K_COUNT] = {0, 0, 0, 0, 0};   // algorithmic flops (GEMM) or bytes (Gram) or pair-terms (Sobol)
@@ -84,7 +85,11 @@ struct RcProfScope {
   RcProfScope(rcgp_handle_s* h_, int cls, double work) : h(h_), idx(-1) {
     if (!h->profiling) return;
     RcProfEvent ev; ev.cls = cls;
-    if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) return;
+    auto take = [&](hipEvent_t* e) {
+      if (!h->event_pool.empty()) { *e = h->event_pool.back(); h->event_pool.pop_back(); return true; }
+      return hipEventCreate(e) == hipSuccess;
+    };
+    if (!take(&ev.start) || !take(&ev.stop)) return;
     (void)hipEventRecord(ev.start, h->stream);
     h->prof_events.push_back(ev);
     idx = (int)h->prof_events.size() - 1;

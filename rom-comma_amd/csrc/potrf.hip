@@ -19,80 +19,155 @@ __device__ __forceinline__ double rc_rsqrt(double d) {
   return y;
 }
 
-__global__ void __launch_bounds__(256) k_diag(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
-                                              double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
-  extern __shared__ double S[];            // [128][DS] block, then diag[128], rsd[128], rv[128]
-  double* diag = S + 128 * DS;
-  double* rsd = diag + 128;
-  double* rv = rsd + 128;
-  const int t = threadIdx.x;
-  double* At = A + j0 * ld + j0;
-  for (int e = t; e < 128 * 128; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    S[r * DS + c] = (c <= r) ? At[(int64_t)r * ld + c] : 0.0;
-  }
-  if (t < 128) rv[t] = rhs[j0 + t];
-  __syncthreads();
-
-  // ---- Cholesky, right-looking column sweep. S[k][k] keeps the running pivot; sqrt goes to diag[].
-  const int ri = t >> 1, rh = t & 1;
-  for (int k = 0; k < 128; ++k) {
-    double d = S[k * DS + k];
+// The 128x128 block is distributed over the 256 threads' registers, 8x8 elements per thread in a 16-cyclic layout
+// (thread (tx, ty) owns rows ty + 16a, columns tx + 16b), so the rank-1 update of a column step is 64 independent
+// register FMAs and the only communication per step is one 128-entry column through LDS and ONE barrier.
+// KB (the 16-column group of the pivot) is a template parameter so that every register index is static.
+template <int KB>
+__device__ __forceinline__ void chol_steps(double (&R)[8][8], double* colbuf, double* rsd, double* diag, int* info, int64_t j0,
+                                           const int tx, const int ty) {
+#pragma unroll 1
+  for (int kx = 0; kx < 16; ++kx) {
+    const int k = KB * 16 + kx;
+    double* buf = colbuf + (k & 1) * 128;
+    if (tx == kx) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) buf[ty + 16 * a] = R[a][KB];
+    }
+    __syncthreads();
+    double d = buf[k];
     if (!(d > 0.0)) {                       // not positive definite (or NaN): flag the leading minor, keep going finite
-      if (t == 0) atomicCAS(info, 0, (int)(j0 + k + 1));
+      if (threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + k + 1));
       d = 1.0;
     }
     const double rs = rc_rsqrt(d);
-    if (t < 128) {
-      if (t > k) S[t * DS + k] *= rs;
-      else if (t == k) { diag[k] = d * rs; rsd[k] = rs; }
+    if (threadIdx.x == 0) { rsd[k] = rs; diag[k] = d * rs; }
+    double li[8], lj[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) li[a] = buf[ty + 16 * a] * rs;
+#pragma unroll
+    for (int b = KB; b < 8; ++b) lj[b] = buf[tx + 16 * b] * rs;
+    if (tx == kx) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) R[a][KB] = li[a];          // final L[i][k] for i > k (row k itself is fixed up from diag[])
     }
-    __syncthreads();
-    if (ri > k) {
-      const double lik = S[ri * DS + k];
-      for (int j = k + 1 + rh; j <= ri; j += 2) S[ri * DS + j] -= lik * S[j * DS + k];
+#pragma unroll
+    for (int b = KB; b < 8; ++b) {
+      if (b == KB && tx <= kx) continue;                      // only columns j > k
+#pragma unroll
+      for (int a = 0; a < 8; ++a) R[a][b] = __builtin_fma(-li[a], lj[b], R[a][b]);
     }
-    __syncthreads();
   }
+}
 
-  // ---- write L back (lower + diagonal; zero above) and log-diagonal
-  for (int e = t; e < 128 * 128; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    At[(int64_t)r * ld + c] = (c < r) ? S[r * DS + c] : (c == r ? diag[r] : 0.0);
-  }
-  if (t < 128) logdiag[j0 + t] = log(diag[t]);
-
-  // ---- inverse X = L^-1 by forward elimination on the identity. X[i][j] (i > j) lives transposed in the upper
-  //      triangle: U(j,i) = S[j*DS + i]; X[i][i] = rsd[i]. (Upper triangle was zero-filled on load.)
-  for (int k = 0; k < 127; ++k) {
-    if (t < k) S[t * DS + k] *= rsd[k];                     // finalise row k of X: X[k][j], j < k
-    __syncthreads();
-    if (ri > k) {
-      const double lik = S[ri * DS + k];                     // L[i][k]
-      for (int j = rh; j <= k; j += 2) {
-        const double xkj = (j == k) ? rsd[k] : S[j * DS + k];
-        S[j * DS + ri] -= lik * xkj;                         // R[i][j] -= L[i][k] X[k][j]
+// Forward elimination on the identity: after step k, row k of X = L^-1 is final. Rows i > k: R[i][j] -= L[i][k] X[k][j].
+template <int KB>
+__device__ __forceinline__ void inv_steps(double (&R)[8][8], const double* S, double* rowbuf, const double* rsd, const int tx,
+                                          const int ty) {
+#pragma unroll 1
+  for (int kx = 0; kx < 16; ++kx) {
+    const int k = KB * 16 + kx;
+    double* buf = rowbuf + (k & 1) * 128;
+    if (ty == kx) {                                           // owners of row k
+      const double rk = rsd[k];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int j = tx + 16 * b;
+        const double x = (j < k) ? R[KB][b] * rk : (j == k ? rk : 0.0);
+        R[KB][b] = x;
+        buf[j] = x;
       }
     }
     __syncthreads();
+    double xj[8];
+#pragma unroll
+    for (int b = 0; b <= KB; ++b) xj[b] = buf[tx + 16 * b];   // X[k][j] is zero for j > k: column groups b > KB untouched
+#pragma unroll
+    for (int a = KB; a < 8; ++a) {
+      if (a == KB && ty <= kx) continue;                      // only rows i > k
+      const double lik = S[(ty + 16 * a) * DS + k];
+#pragma unroll
+      for (int b = 0; b <= KB; ++b) R[a][b] = __builtin_fma(-lik, xj[b], R[a][b]);
+    }
   }
-  if (t < 127) S[t * DS + 127] *= rsd[127];
+}
+
+__global__ void __launch_bounds__(256) k_diag(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
+                                              double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
+  extern __shared__ double S[];            // [128][DS] block, then diag[128], rsd[128], rv[128], buf[2][128]
+  double* diag = S + 128 * DS;
+  double* rsd = diag + 128;
+  double* rv = rsd + 128;
+  double* buf = rv + 128;
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  double* At = A + j0 * ld + j0;
+  double R[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int i = ty + 16 * a, j = tx + 16 * b;
+      R[a][b] = (j <= i) ? At[(int64_t)i * ld + j] : 0.0;
+    }
+  if (t < 128) rv[t] = rhs[j0 + t];
+
+  chol_steps<0>(R, buf, rsd, diag, info, j0, tx, ty);
+  chol_steps<1>(R, buf, rsd, diag, info, j0, tx, ty);
+  chol_steps<2>(R, buf, rsd, diag, info, j0, tx, ty);
+  chol_steps<3>(R, buf, rsd, diag, info, j0, tx, ty);
+  chol_steps<4>(R, buf, rsd, diag, info, j0, tx, ty);
+  chol_steps<5>(R, buf, rsd, diag, info, j0, tx, ty);
+  chol_steps<6>(R, buf, rsd, diag, info, j0, tx, ty);
+  chol_steps<7>(R, buf, rsd, diag, info, j0, tx, ty);
   __syncthreads();
 
-  // ---- outputs: invL (row-major, lower, zeros above) and w_j = X * rhs_j
-  for (int e = t; e < 128 * 128; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    invL[e] = (c < r) ? S[c * DS + r] : (c == r ? rsd[r] : 0.0);
-  }
-  if (t < 128) {
-    double s = rsd[t] * rv[t];
-    for (int j = 0; j < t; ++j) s = fma(S[j * DS + t], rv[j], s);
-    rhs[j0 + t] = s;
+  // L back to global (lower + diagonal, zeros above), a copy into LDS for the inverse sweep, log-diagonal
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int i = ty + 16 * a, j = tx + 16 * b;
+      const double v = (j < i) ? R[a][b] : (j == i ? diag[i] : 0.0);
+      At[(int64_t)i * ld + j] = v;
+      S[i * DS + j] = v;
+      R[a][b] = (i == j) ? 1.0 : 0.0;
+    }
+  if (t < 128) logdiag[j0 + t] = log(diag[t]);
+  __syncthreads();
+
+  inv_steps<0>(R, S, buf, rsd, tx, ty);
+  inv_steps<1>(R, S, buf, rsd, tx, ty);
+  inv_steps<2>(R, S, buf, rsd, tx, ty);
+  inv_steps<3>(R, S, buf, rsd, tx, ty);
+  inv_steps<4>(R, S, buf, rsd, tx, ty);
+  inv_steps<5>(R, S, buf, rsd, tx, ty);
+  inv_steps<6>(R, S, buf, rsd, tx, ty);
+  inv_steps<7>(R, S, buf, rsd, tx, ty);
+  __syncthreads();
+
+  // X = L^-1 out (row-major, zeros above the diagonal) and into LDS for w_j = X * rhs_j
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int i = ty + 16 * a, j = tx + 16 * b;
+      const double v = (j <= i) ? R[a][b] : 0.0;
+      invL[i * 128 + j] = v;
+      S[i * DS + j] = v;
+    }
+  __syncthreads();
+  {
+    // 2 threads per row, each summing half of the (lower-triangular) row
+    const int i = t >> 1, h = t & 1;
+    double s = 0.0;
+    for (int j = h; j <= i; j += 2) s = __builtin_fma(S[i * DS + j], rv[j], s);
+    s += __shfl_xor(s, 1);
+    if (h == 0) rhs[j0 + i] = s;
   }
 }
 
 int rc_launch_diag(rcgp_handle_s* h, int64_t j) {
-  const size_t lds = (size_t)(128 * DS + 3 * 128) * sizeof(double);
+  const size_t lds = (size_t)(128 * DS + 5 * 128) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     RC_HIP(hipFuncSetAttribute((const void*)k_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

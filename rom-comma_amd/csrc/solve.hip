@@ -105,6 +105,7 @@ int rc_lml_value(rcgp_handle_s* h, double* lml) {
   RC_HIP(hipMemcpyAsync(host, h->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   RC_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   RC_HIP(hipStreamSynchronize(h->stream));
+  if (h->profiling) rc_prof_collect(h);      // the stream is idle here: harvesting the events costs no extra sync
   if (info != 0) {
     h->err = "matrix is not positive definite: leading minor " + std::to_string(info);
     h->factored = false;

@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the committed golden fixtures, against the
+oracle on seeded inputs at sizes the oracle finishes in seconds, and -- at the BASELINE.json sizes -- through
+size-independent properties. Tolerance: north_star asks 1e-5 relative in fp64; these tests hold the kernels to 1e-8 or
+tighter so regressions show long before the contract is at risk.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as o          # the checker, never the thing measured
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).resolve().parent / 'golden'
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# golden fixtures (tests/golden/make_golden.py)
+# --------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('name', ['gp_N16_M1', 'gp_N64_M3', 'gp_N256_M10', 'gp_N300_M7'])
+def test_golden_fixture(gpu, name):
+    z = np.load(GOLDEN / f'{name}.npz')
+    gp = gpu.RcGP(z['X'], z['y'])
+    gp.set_hyper(z['ell'], float(z['var']), float(z['noise']))
+    assert gp.lml() == pytest.approx(float(z['lml']), rel=1e-10)
+    lml, grad = gp.lml_grad()
+    assert lml == pytest.approx(float(z['lml']), rel=1e-10)
+    np.testing.assert_allclose(grad, z['grad'], rtol=1e-8, atol=1e-9 * np.max(np.abs(z['grad'])))
+    assert relmax(gp.k_inv_y(), z['alpha']) < 1e-9
+    Lc = gp.k_cho()
+    np.testing.assert_allclose(np.diag(Lc), z['K_cho_diag'], rtol=1e-10)
+    np.testing.assert_allclose(Lc[:8, :8], z['K_cho_corner'], rtol=1e-10, atol=1e-14)
+    assert np.sum(Lc) == pytest.approx(float(z['K_cho_checksum']), rel=1e-10)
+    assert np.all(np.triu(Lc, 1) == 0.0)
+    for flag, km, ks in ((True, 'mean_y', 'sd_y'), (False, 'mean_f', 'sd_f')):
+        m, s = gp.predict(z['Xs'], flag)
+        assert relmax(m, z[km]) < 1e-9
+        np.testing.assert_allclose(s, z[ks], rtol=1e-8)
+    V = gp.sobol_closed(z['slices'])
+    full = abs(z['V'][-2])
+    np.testing.assert_allclose(V, z['V'], rtol=1e-8, atol=1e-9 * full)    # empty slices: V = (sum g)^2 = 0 by centring
+    assert abs(V[-1]) < 1e-9 * full
+    gp.close()
+
+
+def test_literal_multi_output_fixture(gpu):
+    """(L, L) conditional-variance matrix incl. the cross-output entries of the reference's 'lLN,lLNjJn,jJn->lj' einsum
+    (gsa/calibrators.py:79), expected values from the literal transliteration of the TF broadcasting."""
+    z = np.load(GOLDEN / 'sobol_literal_N40_M4_L2.npz')
+    X, Y, ell, F, noise, alpha = z['X'], z['Y'], z['ell'], z['F'], z['noise'], z['alpha']
+    L = Y.shape[1]
+    scale = np.max(np.abs(z['V0']))
+    for l in range(L):
+        gp = gpu.RcGP(X, Y[:, l])
+        gp.set_hyper(ell[l], F[l], noise[l])
+        assert relmax(gp.k_inv_y(), alpha[l]) < 1e-9
+        for j in range(L):
+            V = gp.sobol_closed(z['slices']) if j == l else gp.sobol_cross(ell[j], F[j], alpha[j], z['slices'])
+            np.testing.assert_allclose(V, z['V'][l, j], rtol=1e-7, atol=1e-9 * scale)
+        gp.close()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# oracle on seeded inputs, incl. ragged sizes around the 128 tile edge and the extremes of M
+# --------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('N,M', [(1, 1), (2, 3), (127, 2), (128, 5), (129, 4), (383, 6), (640, 3), (1500, 10), (200, 64), (513, 33)])
+def test_against_oracle(gpu, N, M):
+    X, y = o.synthetic_fold(N, M, k=N % 7)
+    rng = np.random.default_rng(N + M)
+    if N < 8:                                             # the z-scoring in synthetic_fold degenerates for a handful of rows
+        y = rng.standard_normal(N)
+    ell = rng.uniform(0.6, 3.0, M) * (1.0 if M < 20 else np.sqrt(M / 4))       # keep K well away from the identity at large M
+    var, noise = 1.3, 0.015
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(ell, var, noise)
+    assert relmax(gp.gram(), o.noisy_gram(X, ell, var, noise)) < 1e-13
+    assert relmax(gp.k_cho(), o.k_cho(X, ell, var, noise)) < 1e-11
+    lml_ref, grad_ref = o.lml_and_grad(X, y, ell, var, noise)
+    assert gp.lml() == pytest.approx(lml_ref, rel=1e-10, abs=1e-10)
+    lml, grad = gp.lml_grad()
+    assert lml == pytest.approx(lml_ref, rel=1e-10, abs=1e-10)
+    np.testing.assert_allclose(grad, grad_ref, rtol=1e-7, atol=1e-9 * np.max(np.abs(grad_ref)))
+    alpha_ref = o.k_inv_y(X, y, ell, var, noise)
+    assert relmax(gp.k_inv_y(), alpha_ref) < 1e-9
+    Xs, _ = o.synthetic_fold(37, M, k=90)
+    m, s = gp.predict(Xs, True)
+    mr, sr = o.predict(X, y, ell, var, noise, Xs, True)
+    assert relmax(m, mr) < 1e-9
+    np.testing.assert_allclose(s, sr, rtol=1e-8)
+    slices = o.all_slices(M) + ([(1, M - 1)] if M > 3 else [])
+    if M <= 10:
+        V = gp.sobol_closed(slices)
+        g, phi = o.sobol_prepare(X, alpha_ref[None, :], np.array([var]), ell[None, :])
+        Vr = o.sobol_V_pair(X, g[0], g[0], phi[0], phi[0], slices)
+        np.testing.assert_allclose(V, Vr, rtol=1e-7, atol=1e-10 * abs(Vr[-1 if M <= 3 else -2]))
+    else:                                                   # large M: all 3M slices run on the GPU, the oracle checks a few
+        few = [(0, M), (0, 1), (M - 1, M), (3, 7), (0, M // 2), (M // 2, M)]
+        V = gp.sobol_closed(few)
+        g, phi = o.sobol_prepare(X, alpha_ref[None, :], np.array([var]), ell[None, :])
+        Vr = o.sobol_V_pair(X, g[0], g[0], phi[0], phi[0], few)
+        np.testing.assert_allclose(V, Vr, rtol=1e-7, atol=1e-10 * abs(Vr[0]))
+    gp.close()
+
+
+def test_isotropic_kernel_via_repeated_lengthscale(gpu):
+    """Isotropic GPs (the '.i' models, gpr/kernels.py:46-47) are the ARD kernel with one lengthscale repeated."""
+    X, y = o.synthetic_fold(300, 5, k=4)
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(1.7, 0.9, 0.02)
+    lml, grad = gp.lml_grad()
+    lml_ref, grad_ref = o.lml_and_grad(X, y, np.array([1.7]), 0.9, 0.02)
+    assert lml == pytest.approx(lml_ref, rel=1e-10)
+    assert np.sum(grad[:5]) == pytest.approx(grad_ref[0], rel=1e-8)
+    np.testing.assert_allclose(grad[5:], grad_ref[1:], rtol=1e-8)
+    gp.close()
+
+
+def test_set_y_switches_output_without_reupload(gpu):
+    X, y0 = o.synthetic_fold(400, 4, k=1, l=0)
+    _, y1 = o.synthetic_fold(400, 4, k=1, l=1)
+    ell = np.array([0.9, 1.5, 2.5, 3.0])
+    gp = gpu.RcGP(X, y0)
+    gp.set_hyper(ell, 1.0, 0.01)
+    a0 = gp.lml()
+    gp.set_y(y1)
+    a1 = gp.lml()
+    assert a0 == pytest.approx(o.lml(X, y0, ell, 1.0, 0.01), rel=1e-10)
+    assert a1 == pytest.approx(o.lml(X, y1, ell, 1.0, 0.01), rel=1e-10)
+    gp.close()
+
+
+def test_predict_chunking_and_ragged_counts(gpu):
+    X, y = o.synthetic_fold(500, 3, k=2)
+    ell = np.array([0.8, 1.6, 2.4])
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(ell, 1.1, 0.02)
+    for n in (1, 130, 4096 + 77):                       # last one crosses the internal 4096-point chunk
+        Xs, _ = o.synthetic_fold(n, 3, k=33)
+        m, s = gp.predict(Xs, False)
+        mr, sr = o.predict(X, y, ell, 1.1, 0.02, Xs, False)
+        assert relmax(m, mr) < 1e-9
+        np.testing.assert_allclose(s, sr, rtol=1e-7)
+    m, s = gp.predict(np.zeros((0, 3)))
+    assert m.shape == (0,) and s.shape == (0,)
+    gp.close()
+
+
+def test_not_positive_definite_is_reported(gpu):
+    """Duplicate rows with zero noise: K is singular. TensorFlow raises InvalidArgumentError from tf.linalg.cholesky
+    (gpr/models.py:439); the C ABI returns the LAPACK-style index and the binding raises ValueError."""
+    X, y = o.synthetic_fold(200, 2, k=5)
+    X[150] = X[20]
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper([1.0, 1.0], 1.0, 0.0)
+    with pytest.raises(gpu.NotPositiveDefiniteError) as info:
+        gp.lml()
+    assert 1 <= info.value.k <= 200
+    gp.set_hyper([1.0, 1.0], 1.0, 1e-2)                  # the handle stays usable
+    assert np.isfinite(gp.lml())
+    gp.close()
+
+
+def test_argument_errors(gpu):
+    X, y = o.synthetic_fold(64, 2)
+    gp = gpu.RcGP(X, y)
+    with pytest.raises(gpu.RcgpError, match='not set'):
+        gp.lml()
+    with pytest.raises(gpu.RcgpError, match='positive'):
+        gp.set_hyper([1.0, -1.0], 1.0, 0.1)
+    gp.set_hyper([1.0, 2.0], 1.0, 0.1)
+    with pytest.raises(gpu.RcgpError, match='bad slice'):
+        gp.sobol_closed([(1, 5)])
+    with pytest.raises(ValueError):
+        gp.predict(np.zeros((3, 5)))
+    gp.close()
+
+
+def test_exp_accuracy_through_gram(gpu):
+    """rc_exp against numpy. (a) 1-D points in [0, 39]: exponents cover [-760, 0], both sides form r^2 by the expansion
+    |z_i|^2 + |z_j|^2 - 2 z_i z_j, whose rounding (~760 * 2.2e-16 absolute in the exponent) bounds the agreement; exact 0
+    past the fp64 underflow. (b) points in [0, 4]: the expansion is benign and exp itself shows: a few ulp."""
+    x = np.linspace(0.0, 39.0, 1024)[:, None]
+    gp = gpu.RcGP(x, np.zeros(1024))
+    gp.set_hyper([1.0], 1.0, 0.0)
+    K = gp.gram()
+    ref = o.gram(x, np.array([1.0]), 1.0)
+    big = ref > 1e-300
+    assert np.max(np.abs(K[big] - ref[big]) / ref[big]) < 1e-12
+    assert np.all(K[ref == 0.0] == 0.0)
+    gp.close()
+    x = np.linspace(0.0, 4.0, 1024)[:, None]
+    gp = gpu.RcGP(x, np.zeros(1024))
+    gp.set_hyper([1.0], 1.0, 0.0)
+    K = gp.gram()
+    ref = np.exp(-0.5 * (x - x.T) ** 2)                    # difference form: the accurate value
+    assert np.max(np.abs(K - ref) / ref) < 1e-14
+    gp.close()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# BASELINE.json sizes: size-independent properties (the oracle cannot run these in seconds)
+# --------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('N,M', [(8192, 5), (16384, 10)])
+def test_full_size_properties(gpu, N, M):
+    X, y = o.synthetic_fold(N, M)
+    ell, var, noise = o.bench_hyper(M)
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(ell, var, noise)
+    lml, grad = gp.lml_grad()
+    assert np.isfinite(lml) and np.all(np.isfinite(grad))
+    # (1) K alpha = y - noise alpha  <=>  predict_f mean at training points (check_K_inv_Y, gpr/models.py:446-463)
+    idx = np.random.default_rng(0).choice(N, 256, replace=False)
+    alpha = gp.k_inv_y()
+    mean, sd = gp.predict(X[idx], False)
+    np.testing.assert_allclose(mean, y[idx] - noise * alpha[idx], rtol=0, atol=2e-8 * np.max(np.abs(y)))
+    assert np.all(sd ** 2 <= noise * 1.000001) and np.all(sd >= 0)      # posterior f-variance at a training point < noise
+    # (2) the gradient is the derivative of the LML: central difference along one lengthscale, the variance and the noise
+    for p, h in ((0, 1e-5), (M, 1e-5), (M + 1, 1e-7)):
+        def at(delta):
+            e, v, n_ = ell.copy(), var, noise
+            if p < M:
+                e[p] += delta
+            elif p == M:
+                v += delta
+            else:
+                n_ += delta
+            gp.set_hyper(e, v, n_)
+            return gp.lml()
+        fd = (at(h) - at(-h)) / (2 * h)
+        assert grad[p] == pytest.approx(fd, rel=2e-4), f'parameter {p}'
+    gp.set_hyper(ell, var, noise)
+    # (3) Sobol invariants (gsa/calibrators.py:90,97; gsa/models.py:207-214)
+    V = gp.sobol_closed(o.all_slices(M) + [(M, M)])
+    first, closed, comp, full, empty = V[:M], V[M:2 * M], V[2 * M:3 * M], V[3 * M], V[3 * M + 1]
+    assert full > 0 and abs(empty) < 1e-9 * full
+    assert closed[M - 1] == pytest.approx(full, rel=1e-12)
+    assert first[0] == pytest.approx(closed[0], rel=1e-12)
+    assert np.all(np.diff(closed) >= -1e-9 * full)
+    assert np.all(first <= closed + 1e-9 * full)
+    total = 1.0 - comp / full
+    assert np.all(total >= first / full - 1e-7)
+    gp.close()

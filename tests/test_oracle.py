@@ -1,0 +1,192 @@
+"""CPU tests of the oracle itself (no GPU): internal cross-checks that stand in for the reference's absent golden vectors.
+
+The reference ships no assertions for this path; the invariants its author checks by hand
+(check_K_inv_Y ~ 0, S_full = 1, V_empty = 0, symmetry) are the unit tests here, plus: literal TF-broadcast transliteration
+== closed form, analytic gradient == finite differences, mpmath 50-digit LML / V_S, and the committed golden fixtures.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as o
+
+GOLDEN = Path(__file__).resolve().parent / 'golden'
+
+
+def _two_output_setup(N=40, M=4, L=2, seed=3):
+    X, _ = o.synthetic_fold(N, M, k=seed)
+    rng = np.random.default_rng(7)
+    ell = rng.uniform(0.5, 3.0, (L, M))
+    F = rng.uniform(0.5, 2.0, L)
+    noise = [0.01, 0.02]
+    alpha = np.stack([o.k_inv_y(X, o.synthetic_fold(N, M, k=seed, l=l)[1], ell[l], F[l], noise[l]) for l in range(L)])
+    return X, alpha, F, ell
+
+
+def test_literal_transliteration_matches_closed_form():
+    X, alpha, F, ell = _two_output_setup()
+    M = X.shape[1]
+    lit = o.LiteralClosedSobol(X, alpha[:, None, :], F[None, :], ell)
+    clo = o.ClosedSobolOracle(X, alpha[:, None, :], F[None, :], ell)
+    np.testing.assert_allclose(clo.V[0], lit.V[0], rtol=1e-9)
+    for sl in [(0, M), (0, 1), (1, 2), (0, 3), (2, M), (1, 3)]:
+        np.testing.assert_allclose(clo.marginalize(sl)['V'], lit.marginalize(sl)['V'], rtol=1e-8, atol=1e-13)
+    # empty slice: exactly the centring property V_empty = (sum g)^2 = 0 (gsa/calibrators.py:90)
+    assert np.max(np.abs(lit.marginalize((M, M))['V'])) < 1e-10
+    assert np.max(np.abs(clo.marginalize((M, M))['V'])) < 1e-10
+
+
+def test_sobol_invariants():
+    X, alpha, F, ell = _two_output_setup(N=64, M=5)
+    M = X.shape[1]
+    cal = o.ClosedSobolOracle(X, alpha[:, None, :], F[None, :], ell)
+    np.testing.assert_allclose(np.diag(cal.S), 1.0, rtol=1e-12)                 # S_full = 1 (gsa/calibrators.py:97)
+    np.testing.assert_allclose(cal.V[0], cal.V[0].T, rtol=1e-9)                 # symmetric in (l, j)
+    res = {k: o.gsa_calibrate(cal, k, M) for k in (o.FIRST_ORDER, o.CLOSED, o.TOTAL)}
+    for l in range(2):
+        first, closed, total = (res[k]['S'][l, l] for k in (o.FIRST_ORDER, o.CLOSED, o.TOTAL))
+        assert np.all(np.diff(closed[:M]) >= -1e-12)                           # closed index non-decreasing in m
+        assert np.all(first[:M] <= closed[:M] + 1e-12)
+        assert np.all(total[:M] >= first[:M] - 1e-9)
+        np.testing.assert_allclose(closed[M - 1], 1.0, rtol=1e-12)
+        np.testing.assert_allclose([first[M], closed[M], total[M]], 1.0, rtol=1e-12)   # appended full-model column
+        np.testing.assert_allclose(first[0], closed[0], rtol=1e-12)
+        np.testing.assert_allclose(total[M - 1], 1.0, rtol=1e-9)                # 1 - S_empty
+
+
+def test_gradient_matches_finite_differences():
+    X, y = o.synthetic_fold(48, 3, k=5)
+    theta = np.array([0.8, 1.7, 2.9, 1.3, 0.02])
+    value, grad = o.lml_and_grad(X, y, theta[:3], theta[3], theta[4])
+    assert value == pytest.approx(o.lml(X, y, theta[:3], theta[3], theta[4]), rel=1e-13)
+    fd = np.empty_like(theta)
+    for i in range(len(theta)):
+        h = 1e-6 * theta[i]
+        tp, tm = theta.copy(), theta.copy()
+        tp[i] += h
+        tm[i] -= h
+        fd[i] = (o.lml(X, y, tp[:3], tp[3], tp[4]) - o.lml(X, y, tm[:3], tm[3], tm[4])) / (2 * h)
+    np.testing.assert_allclose(grad, fd, rtol=2e-6)
+
+
+def test_isotropic_gradient_and_unconstrained_chain_rule():
+    X, y = o.synthetic_fold(40, 4, k=6)
+    v, g = o.lml_and_grad(X, y, np.array([1.4]), 1.1, 0.03)
+    v2, g2 = o.lml_and_grad(X, y, np.full(4, 1.4), 1.1, 0.03)
+    assert v == pytest.approx(v2, rel=1e-14)
+    assert g[0] == pytest.approx(np.sum(g2[:4]), rel=1e-12)
+    u = o.pack_unconstrained(np.full(4, 1.4), 1.1, 0.03)
+    ell, var, noise = o.unpack_unconstrained(u)
+    np.testing.assert_allclose(ell, 1.4, rtol=1e-13)
+    assert (var, noise) == (pytest.approx(1.1, rel=1e-13), pytest.approx(0.03, rel=1e-12))
+    f0, gu = o.neg_lml_unconstrained(u, X, y)
+    for i in range(len(u)):
+        up, um = u.copy(), u.copy()
+        up[i] += 1e-6
+        um[i] -= 1e-6
+        fd = (o.neg_lml_unconstrained(up, X, y)[0] - o.neg_lml_unconstrained(um, X, y)[0]) / 2e-6
+        assert gu[i] == pytest.approx(fd, rel=5e-6, abs=1e-8)
+
+
+def test_mpmath_lml_and_sobol():
+    """50-digit evaluation of the same formulas at N=12: fp64 oracle agrees to ~1e-10 (conditioning-limited)."""
+    mp = pytest.importorskip('mpmath')
+    mp.mp.dps = 50
+    N, M = 12, 2
+    X, y = o.synthetic_fold(N, M, k=9)
+    ell, var, noise = np.array([0.9, 2.1]), 1.2, 0.05
+    Xm = [[mp.mpf(float(v)) for v in row] for row in X]
+    K = mp.matrix(N, N)
+    for i in range(N):
+        for j in range(N):
+            r2 = sum(((Xm[i][m] - Xm[j][m]) / mp.mpf(float(ell[m]))) ** 2 for m in range(M))
+            K[i, j] = mp.mpf(var) * mp.exp(-r2 / 2) + (mp.mpf(noise) if i == j else 0)
+    ym = mp.matrix([mp.mpf(float(v)) for v in y])
+    Lm = mp.cholesky(K)
+    alpha = mp.lu_solve(K, ym)
+    lml = -(ym.T * alpha)[0] / 2 - sum(mp.log(Lm[i, i]) for i in range(N)) - mp.mpf(N) / 2 * mp.log(2 * mp.pi)
+    assert o.lml(X, y, ell, var, noise) == pytest.approx(float(lml), rel=1e-11)
+    np.testing.assert_allclose(o.k_inv_y(X, y, ell, var, noise), [float(a) for a in alpha], rtol=1e-9)
+    # Sobol V for slices, by the Gaussian-ratio definition (gsa/calibrators.py:69-79) in 50 digits
+    phi = [1 / (mp.mpf(float(l)) ** 2 + 1) for l in ell]
+    pre = mp.mpf(var) * mp.sqrt(mp.fprod([mp.mpf(float(l)) ** 2 * p for l, p in zip(ell, phi)]))
+    g0 = [pre * mp.exp(-sum(phi[m] * Xm[n][m] ** 2 for m in range(M)) / 2) for n in range(N)]
+    g = [g0[n] * alpha[n] for n in range(N)]
+    gbar = sum(g) / N
+    g = [v - gbar for v in g]
+
+    def V(lo, hi):
+        tot = mp.mpf(0)
+        for n in range(N):
+            for n2 in range(N):
+                h = mp.mpf(1)
+                for m in range(lo, hi):
+                    G1, G2, p = phi[m] * Xm[n][m], phi[m] * Xm[n2][m], phi[m]
+                    psi = 1 - p * p                                    # Gamma + Gamma - Gamma^2 with Gamma = 1 - phi
+                    num = mp.exp(-(G1 - p * G2) ** 2 / (2 * psi * p)) / mp.sqrt(psi * p)
+                    den = mp.exp(-G1 ** 2 / (2 * p)) / mp.sqrt(p)
+                    h *= num / den
+                tot += g[n] * h * g[n2]
+        return tot
+    a = o.k_inv_y(X, y, ell, var, noise)
+    cal = o.ClosedSobolOracle(X, a[None, None, :], np.array([[var]]), ell[None, :])
+    for sl in [(0, 2), (0, 1), (1, 2)]:
+        assert cal.marginalize(sl)['V'][0, 0] == pytest.approx(float(V(*sl)), rel=1e-8)
+
+
+def test_check_k_inv_y_is_zero():
+    X, y = o.synthetic_fold(80, 3, k=2)
+    Xs, _ = o.synthetic_fold(11, 3, k=12)
+    assert o.check_k_inv_y(X, y, np.array([1.0, 2.0, 0.7]), 1.5, 0.02, Xs) < 1e-11      # gpr/models.py:446-463
+
+
+def test_gsa_slices_match_reference_definition():
+    assert o.gsa_slices(o.FIRST_ORDER, 3) == [(0, 1), (1, 2), (2, 3)]                   # gsa/models.py:84-85
+    assert o.gsa_slices(o.CLOSED, 3) == [(0, 1), (0, 2), (0, 3)]                        # :86-87
+    assert o.gsa_slices(o.TOTAL, 3) == [(1, 3), (2, 3), (3, 3)]                         # :88-89
+    assert o.gsa_slices(o.TOTAL, 3, m=1) == [(2, 3)]
+    assert len(o.all_slices(10)) == 31
+
+
+def test_known_answer_sobol_additive_function():
+    """Sanity (not parity): for f = sum_m a_m sin(x_m) with x ~ N(0, I) the first-order index of input m is
+    a_m^2 / sum a^2 (every term has the same variance (1 - e^-2)/2). A GP fitted on 300 noisy samples reproduces it to
+    GP-approximation accuracy."""
+    rng = np.random.default_rng(11)
+    N, M = 300, 3
+    X = rng.standard_normal((N, M))
+    a = np.array([3.0, 2.0, 1.0])
+    f = np.sin(X) @ a
+    y = (f - f.mean()) / f.std() + 0.01 * rng.standard_normal(N)
+    fit = o.fit(X, y, np.full(M, 5.0))
+    alpha = o.k_inv_y(X, y, fit['ell'], fit['var'], fit['noise'])
+    cal = o.ClosedSobolOracle(X, alpha[None, None, :], np.array([[fit['var']]]), fit['ell'][None, :])
+    S = o.gsa_calibrate(cal, o.FIRST_ORDER, M)['S'][0, 0, :M]
+    np.testing.assert_allclose(S, a ** 2 / np.sum(a ** 2), atol=0.03)
+
+
+@pytest.mark.parametrize('name', ['gp_N16_M1', 'gp_N64_M3', 'gp_N256_M10', 'gp_N300_M7'])
+def test_oracle_reproduces_golden(name):
+    z = np.load(GOLDEN / f'{name}.npz')
+    X, y, ell, var, noise = z['X'], z['y'], z['ell'], float(z['var']), float(z['noise'])
+    lml, grad = o.lml_and_grad(X, y, ell, var, noise)
+    assert lml == pytest.approx(float(z['lml']), rel=1e-12)
+    np.testing.assert_allclose(grad, z['grad'], rtol=1e-9)
+    np.testing.assert_allclose(o.k_inv_y(X, y, ell, var, noise), z['alpha'], rtol=1e-9, atol=1e-9 * np.max(np.abs(z['alpha'])))
+    m, s = o.predict(X, y, ell, var, noise, z['Xs'], True)
+    np.testing.assert_allclose(m, z['mean_y'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(s, z['sd_y'], rtol=1e-9)
+    alpha = z['alpha']
+    g, phi = o.sobol_prepare(X, alpha[None, :], np.array([var]), ell[None, :])
+    V = o.sobol_V_pair(X, g[0], g[0], phi[0], phi[0], z['slices'])
+    np.testing.assert_allclose(V[:-1], z['V'][:-1], rtol=1e-9)
+    assert abs(V[-1]) < 1e-9 * abs(z['V'][-2])
+
+
+def test_literal_golden_fixture():
+    z = np.load(GOLDEN / 'sobol_literal_N40_M4_L2.npz')
+    clo = o.ClosedSobolOracle(z['X'], z['alpha'][:, None, :], z['F'][None, :], z['ell'])
+    for s, sl in enumerate(z['slices']):
+        np.testing.assert_allclose(clo.marginalize(sl)['V'], z['V'][..., s], rtol=1e-8, atol=1e-10 * np.max(np.abs(z['V0'])))
+    np.testing.assert_allclose(clo.S, z['S'], rtol=1e-9)
