@@ -1,20 +1,24 @@
-// Micro-benchmark: sustained v_mfma_f64_16x16x4_f64 rate and fp64 VALU FMA rate on every CU (peak calibration for roofline).
+// Micro-benchmark: sustained v_mfma_f64_16x16x4_f64 rate (and the in-kernel clock it runs at) and the fp64 VALU FMA rate on
+// every CU -- peak calibration for the roofline fractions quoted in DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 template <int NACC>
-__global__ void __launch_bounds__(256) k_mfma(double* out, int iters) {
+__global__ void __launch_bounds__(256) k_mfma(double* out, int iters, unsigned long long* clk) {
   v4d acc[NACC];
   for (int i = 0; i < NACC; ++i) acc[i] = (v4d){0, 0, 0, 0};
   double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
   }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   double s = 0;
   for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
 __global__ void __launch_bounds__(256) k_fma(double* out, int iters) {
@@ -33,31 +37,43 @@ __global__ void __launch_bounds__(256) k_fma(double* out, int iters) {
 template <typename F>
 static float time_ms(F f) {
   hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   f();
-  hipDeviceSynchronize();
-  hipEventRecord(e0);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
   f();
-  hipEventRecord(e1);
-  hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   return ms;
 }
 
+template <int NACC>
+static void run_mfma(double* out, unsigned long long* clk, int wg_per_cu, int threads) {
+  const int iters = 20000, blocks = 256 * wg_per_cu;
+  float ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<NACC>, dim3(blocks), dim3(threads), 0, 0, out, iters, clk); });
+  unsigned long long h[2];
+  (void)hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+  const double ghz = (double)h[0] / (double)h[1] * 0.1;      // s_memrealtime ticks at 100 MHz
+  const double waves_per_simd = wg_per_cu * threads / 256.0;
+  const double flops = (double)blocks * (threads / 64) * iters * NACC * 2048.0;
+  printf("mfma_f64_16x16x4 acc=%d waves/SIMD=%.0f: %6.2f TFLOP/s, in-kernel clock %.2f GHz, %.1f cycles/mfma/SIMD at that clock\n", NACC,
+         waves_per_simd, flops / ms / 1e9, ghz, (double)h[0] / ((double)iters * NACC * waves_per_simd));
+}
+
 int main() {
-  double* out; hipMalloc(&out, 4096 * 256 * sizeof(double));
+  double* out; (void)hipMalloc(&out, 8192 * 512 * sizeof(double));
+  unsigned long long* clk; (void)hipMalloc(&clk, 8192 * 2 * sizeof(unsigned long long));
+  run_mfma<1>(out, clk, 1, 256);
+  run_mfma<4>(out, clk, 1, 256);
+  run_mfma<8>(out, clk, 1, 256);
+  run_mfma<16>(out, clk, 1, 256);
+  run_mfma<4>(out, clk, 2, 256);
+  run_mfma<16>(out, clk, 2, 256);
+  run_mfma<4>(out, clk, 4, 256);
+  run_mfma<4>(out, clk, 8, 256);
   const int iters = 20000;
-  for (int wg_per_cu = 1; wg_per_cu <= 2; ++wg_per_cu) {
-    const int blocks = 256 * wg_per_cu;
-    float ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<4>, dim3(blocks), dim3(256), 0, 0, out, iters); });
-    double flops = (double)blocks * 4 /*waves*/ * iters * 4 /*acc*/ * 2048.0;
-    printf("mfma_f64 16x16x4, 4 acc, %d waves/SIMD: %.2f TFLOP/s (%.1f cycles/mfma/SIMD @2.4GHz)\n", wg_per_cu, flops / ms / 1e9,
-           ms * 1e-3 * 2.4e9 / ((double)wg_per_cu * iters * 4));
-    ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<1>, dim3(blocks), dim3(256), 0, 0, out, iters); });
-    flops = (double)blocks * 4 * iters * 1 * 2048.0;
-    printf("mfma_f64 16x16x4, 1 acc (dependent), %d waves/SIMD: %.2f TFLOP/s\n", wg_per_cu, flops / ms / 1e9);
-  }
-  for (int wg_per_cu = 1; wg_per_cu <= 4; wg_per_cu *= 2) {
+  for (int wg_per_cu = 1; wg_per_cu <= 8; wg_per_cu *= 2) {
     const int blocks = 256 * wg_per_cu;
     float ms = time_ms([&] { hipLaunchKernelGGL(k_fma, dim3(blocks), dim3(256), 0, 0, out, iters); });
     double flops = (double)blocks * 256 * iters * 16 * 2.0;
