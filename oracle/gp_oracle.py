@@ -21,6 +21,7 @@ from typing import Dict, Iterable, List, Sequence, Tuple
 import numpy as np
 import scipy.linalg
 import scipy.optimize
+import scipy.special
 
 LOG_2PI = math.log(2.0 * math.pi)
 
@@ -76,8 +77,7 @@ def inv_softplus(x):
 
 
 def sigmoid(u):
-    u = np.asarray(u, dtype=np.float64)
-    return 0.5 * (1.0 + np.tanh(0.5 * u))
+    return scipy.special.expit(np.asarray(u, dtype=np.float64))
 
 
 # --------------------------------------------------------------------------------------------------------------------

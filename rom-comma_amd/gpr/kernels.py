@@ -1,0 +1,111 @@
+"""Kernel parameter store (reference gpr/kernels.py:30-180). A Kernel is a Model whose Data are the kernel variance,
+(1,L) for independent outputs, and the lengthscales, (L,M) anisotropic or (L,1) isotropic. In the reference
+``implementation`` builds GPflow kernel objects; here it yields plain per-output parameter records that the HIP-backed GP
+pushes to the device with ``rcgp_set_hyper`` -- the kernel arithmetic itself lives in csrc/gram.hip.
+"""
+from __future__ import annotations
+
+from abc import abstractmethod
+from pathlib import Path
+from typing import Any, Dict, NamedTuple, Tuple, Type
+
+import numpy as np
+
+from romcomma_amd.base.classes import Data, Model
+
+
+class Kernel(Model):
+    """Abstract kernel: the code contract with the GPR interface."""
+
+    class Data(Data):
+        class NamedTuple(NamedTuple):
+            variance: Any = np.atleast_2d(2.0)          # reference default, gpr/kernels.py:49
+            lengthscales: Any = np.atleast_2d(5.0)      # reference default, gpr/kernels.py:50
+
+    @classmethod
+    @property
+    def META(cls) -> Dict[str, Any]:
+        return {'variance': True, 'covariance': False, 'lengthscales': {'variant': True, 'covariant': False}}
+
+    VARIANCE_FLOOR: float = 1.0005E-6                   # gpr/kernels.py:176
+
+    def __init__(self, folder: Path | str, read_data: bool = False, **kwargs: Any):
+        super().__init__(folder, read_data, **kwargs)
+        variance_shape = self._data.frames.variance.df.shape
+        self._L, self._M = variance_shape[1], self._data.frames.lengthscales.df.shape[1]
+        self._trainable = self.META
+        self.broadcast_parameters(variance_shape, self._M)
+
+    def calibrate(self, **kwargs: Any) -> Dict[str, Any]:
+        """Records which hyper-parameters are trainable; returns the merged options (gpr/kernels.py:59-70)."""
+        self._trainable = self.META | kwargs
+        return self._trainable
+
+    @property
+    def trainable(self) -> Dict[str, Any]:
+        return self._trainable
+
+    @classmethod
+    @property
+    def TYPE_IDENTIFIER(cls) -> str:
+        """``<module>.<class>``, e.g. 'kernels.RBF': the string stored in ``<gp>/kernel.csv`` (gpr/kernels.py:72-76)."""
+        return cls.__module__.split('.')[-1] + '.' + cls.__name__
+
+    @classmethod
+    def TypeFromIdentifier(cls, TypeIdentifier: str) -> Type['Kernel']:
+        for kernel_type in cls.__subclasses__():
+            if kernel_type.TYPE_IDENTIFIER == TypeIdentifier:
+                return kernel_type
+        raise TypeError('Kernel.TypeIdentifier() of unrecognizable type.')
+
+    @classmethod
+    def TypeFromParameters(cls, parameters: Data) -> Type['Kernel']:
+        for kernel_type in cls.__subclasses__():
+            if isinstance(parameters, kernel_type.Data):
+                return kernel_type
+        raise TypeError('Kernel Data array of unrecognizable type.')
+
+    @property
+    def L(self) -> int:
+        return self._L
+
+    @property
+    def M(self) -> int:
+        return self._M
+
+    @property
+    def is_covariant(self) -> bool:
+        return self._data.frames.variance.df.shape[0] > 1
+
+    def broadcast_parameters(self, variance_shape: Tuple[int, int], M: int) -> 'Kernel':
+        """Broadcast to more outputs / input dimensions; shrinking raises IndexError (gpr/kernels.py:121-139)."""
+        if tuple(variance_shape) != self._data.frames.variance.df.shape:
+            self._data.frames.variance.broadcast_value(target_shape=tuple(variance_shape), is_diagonal=True)
+            self._L = variance_shape[1]
+        if (self._L, M) != self._data.frames.lengthscales.df.shape:
+            self._data.frames.lengthscales.broadcast_value(target_shape=(self._L, M), is_diagonal=False)
+            self._M = M
+        self._implementation = None
+        self._implementation = self.implementation
+        return self
+
+    @property
+    @abstractmethod
+    def implementation(self) -> Tuple[Any, ...]:
+        """One record per independent output."""
+
+
+class RBF(Kernel):
+    """ARD squared-exponential kernel k(x,x') = variance * exp(-1/2 sum_m (x_m - x'_m)^2 / lengthscale_m^2)."""
+
+    @property
+    def implementation(self) -> Tuple[Dict[str, Any], ...]:
+        variance = self._data.frames.variance.np
+        lengthscales = self._data.frames.lengthscales.np
+        if self._implementation is None:
+            if variance.shape[0] != 1:
+                raise NotImplementedError('covariant (L,L) kernel variance: only independent outputs are implemented on this backend')
+            self._implementation = tuple({'variance': max(float(variance[0, l]), self.VARIANCE_FLOOR),
+                                          'lengthscales': np.asarray(lengthscales[l], dtype=float).copy()}
+                                         for l in range(variance.shape[1]))
+        return self._implementation

@@ -1,0 +1,371 @@
+"""GP regression models: the ``GPR`` plugin contract and ``HipGP``, its MI355X implementation.
+
+``GPR`` restates the abstract interface of reference gpr/models.py:88-320 (same constructor signature, same abstract members,
+same inherited helpers and on-disk side effects). ``HipGP`` stands where the reference's GPflow-backed ``MOGP`` stands
+(gpr/models.py:324-463): every numeric step -- Gram matrix, Cholesky, solves, log marginal likelihood and its gradient,
+prediction -- runs in librcgp.so on the GPU; this file only moves parameters between the CSV store and the C ABI.
+``MOGP`` is exported as an alias so existing ``run`` scripts resolve the same name.
+"""
+from __future__ import annotations
+
+from abc import abstractmethod
+from pathlib import Path
+from typing import Any, Dict, NamedTuple, Tuple
+
+import numpy as np
+import pandas as pd
+
+from romcomma_amd import _lib
+from romcomma_amd.base.classes import Data, Frame, Model
+from romcomma_amd.data.storage import Fold
+from romcomma_amd.data.storage import Frame as DataFrameCSV
+from romcomma_amd.gpr.kernels import Kernel
+from romcomma_amd.gpr.optimize import fit_lbfgsb
+
+
+class Likelihood(Model):
+    """Gaussian likelihood (noise) variance store (gpr/models.py:35-84)."""
+
+    class Data(Data):
+        class NamedTuple(NamedTuple):
+            variance: Any = np.atleast_2d(0.02)          # (1,L) independent noise variances; reference default 0.02
+            log_marginal: Any = np.atleast_2d(1.0)       # output: the log marginal likelihood after calibration
+
+    @classmethod
+    @property
+    def META(cls) -> Dict[str, Any]:
+        return {'variance': True, 'covariance': True}
+
+    VARIANCE_FLOOR: float = 1.0001E-6                    # gpr/models.py:62-65
+
+    def __init__(self, parent: 'GPR', read_data: bool = False, **kwargs: Any):
+        super().__init__(parent.folder / 'likelihood', read_data, **kwargs)
+        self._parent = parent
+        self._trainable = self.META
+
+    @property
+    def is_covariant(self) -> bool:
+        return self._data.frames.variance.df.shape[0] > 1
+
+    def calibrate(self, **kwargs: Any) -> Dict[str, Any]:
+        """Records whether the noise variance is trainable (gpr/models.py:71-80)."""
+        self._trainable = self.META | kwargs
+        return self._trainable
+
+    @property
+    def trainable(self) -> Dict[str, Any]:
+        return self._trainable
+
+
+class GPR(Model):
+    """Interface to a Gaussian Process (gpr/models.py:88-320)."""
+
+    class Data(Data):
+        class NamedTuple(NamedTuple):
+            kernel: Any = np.atleast_2d(None)            # [[type identifier]], e.g. 'kernels.RBF'; never set externally
+
+    KERNEL_FOLDER_NAME: str = 'kernel'
+
+    def __init__(self, name: str, fold: Fold, is_read: bool | None, is_covariant: bool, is_isotropic: bool,
+                 kernel_parameters: Kernel.Data | None = None, likelihood_variance: np.ndarray | None = None):
+        """Pulls X (N,M) and Y (N,L) from ``fold`` as float64 copies, builds the Likelihood and Kernel stores under
+        ``fold.folder / name`` and broadcasts them to (1,L) variances and (L,M) or (L,1) lengthscales (gpr/models.py:290-320)."""
+        self._fold = fold
+        self._X = self._fold.X.to_numpy(dtype=np.float64, copy=True)
+        self._Y = self._fold.Y.to_numpy(dtype=np.float64, copy=True)
+        self._N, self._M, self._L = self._fold.N, self._fold.M, self._fold.L
+        super().__init__(self._fold.folder / name, is_read)
+        self._likelihood = Likelihood(self, is_read) if likelihood_variance is None else Likelihood(self, is_read, variance=likelihood_variance)
+        if is_read and kernel_parameters is None:
+            KernelType = Kernel.TypeFromIdentifier(self.data.frames.kernel.np[0, 0])
+            self._kernel = KernelType(self._folder / self.KERNEL_FOLDER_NAME, is_read)
+        else:
+            if kernel_parameters is None:
+                kernel_parameters = Kernel.Data(self._folder / self.KERNEL_FOLDER_NAME)
+            KernelType = Kernel.TypeFromParameters(kernel_parameters)
+            self._kernel = KernelType(self._folder / self.KERNEL_FOLDER_NAME, is_read, **kernel_parameters.asdict())
+            self._data.replace(kernel=np.atleast_2d(KernelType.TYPE_IDENTIFIER))
+        self.broadcast_parameters(is_covariant, is_isotropic)
+
+    # ---- plain accessors
+    @classmethod
+    @property
+    @abstractmethod
+    def META(cls) -> Dict[str, Any]:
+        """Hyper-parameter optimiser options."""
+
+    @property
+    def fold(self) -> Fold:
+        return self._fold
+
+    @property
+    def test_csv(self) -> Path:
+        return self._folder / 'test.csv'
+
+    @property
+    def test_summary_csv(self) -> Path:
+        return self._folder / 'test_summary.csv'
+
+    @property
+    def kernel(self) -> Kernel:
+        return self._kernel
+
+    @property
+    def likelihood(self) -> Likelihood:
+        return self._likelihood
+
+    @property
+    def L(self) -> int:
+        return self._L
+
+    @property
+    def M(self) -> int:
+        return self._M
+
+    @property
+    def N(self) -> int:
+        return self._N
+
+    # ---- the contract an implementation must fulfil
+    @property
+    @abstractmethod
+    def implementation(self) -> Tuple[Any, ...]:
+        """The backend objects behind this GP."""
+
+    @property
+    @abstractmethod
+    def X(self) -> Any:
+        """Training inputs (N,M)."""
+
+    @property
+    @abstractmethod
+    def Y(self) -> Any:
+        """Training outputs (N,L)."""
+
+    @property
+    @abstractmethod
+    def K_cho(self) -> np.ndarray:
+        """Cholesky factor of kernel(X,X) + noise: (L,N,N) for independent outputs."""
+
+    @property
+    @abstractmethod
+    def K_inv_Y(self) -> np.ndarray:
+        """(L,1,N): ChoSolve(K_cho, Y)."""
+
+    @abstractmethod
+    def calibrate(self, **kwargs) -> Dict[str, Any]:
+        raise NotImplementedError
+
+    @abstractmethod
+    def predict(self, x: np.ndarray, y_instead_of_f: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """(mean (o,L), standard deviation (o,L)) at the (o,M) inputs ``x``."""
+
+    @abstractmethod
+    def predict_gradient(self, x: np.ndarray, y_instead_of_f: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """Gradient GP dy/dx."""
+
+    # ---- inherited helpers (pure host code)
+    def predict_df(self, x: np.ndarray, y_instead_of_f: bool = True, is_normalized: bool = True) -> pd.DataFrame:
+        """Prediction as a frame with columns (X, Mean, SD), optionally un-normalised (gpr/models.py:202-222)."""
+        Y_heading = self._fold.meta['data']['Y_heading']
+        mean, sd = self.predict(x, y_instead_of_f)
+        result = pd.DataFrame(np.concatenate([x, mean], axis=1), columns=self._fold.test_data.df.columns)
+        predictive_std = result.loc[:, [Y_heading]].copy()
+        predictive_std.iloc[:] = sd
+        if not is_normalized:
+            result = self._fold.normalization.undo_from(result)
+            predictive_std = self._fold.normalization.unscale_Y(predictive_std)
+        result = result.rename(columns={Y_heading: 'Mean'}, level=0)
+        predictive_std = predictive_std.rename(columns={Y_heading: 'SD'}, level=0)
+        return result.join([predictive_std])
+
+    def test(self) -> DataFrameCSV:
+        """Score the GP on the fold's held-out rows: per row Mean, SD, Abs Error, Z Score, Outlier (Z^2 > 4, plus Any/All
+        outputs) -> ``test.csv``; per output RMSE, mean SD, outlier fraction -> ``test_summary.csv`` (gpr/models.py:235-272)."""
+        Y_heading = self._fold.meta['data']['Y_heading']
+        frame = DataFrameCSV(self.test_csv, self._fold.test_data.df.copy())
+        truth = frame.df.loc[:, [Y_heading]]
+        mean, sd = self.predict(self._fold.test_x.values)
+
+        def like_truth(values, label: str) -> pd.DataFrame:
+            columns = truth.rename(columns={Y_heading: label}, level=0).columns
+            return pd.DataFrame(np.asarray(values), index=truth.index, columns=columns)
+        error = truth.to_numpy(dtype=float) - mean
+        z = error / sd
+        outlier = z ** 2 > 4.0
+        outliers = like_truth(outlier, 'Outlier')
+        outliers[('Outlier', 'Any Output')] = np.logical_or.reduce(outlier, axis=1)
+        outliers[('Outlier', 'All Outputs')] = np.logical_and.reduce(outlier, axis=1)
+        frame.df = frame.df.join([like_truth(mean, 'Mean'), like_truth(sd, 'SD'), like_truth(np.abs(error), 'Abs Error'),
+                                  like_truth(z, 'Z Score'), outliers])
+        frame.write()
+        rmse = pd.DataFrame(like_truth(error ** 2, 'RMSE').mean(axis=0) ** 0.5).transpose()
+        mean_sd = pd.DataFrame(like_truth(sd, 'SD').mean(axis=0)).transpose()
+        fraction = pd.DataFrame(outliers.mean(axis=0)).transpose()
+        DataFrameCSV(self.test_summary_csv, rmse.join([mean_sd, fraction]))
+        return frame
+
+    def broadcast_parameters(self, is_covariant: bool, is_isotropic: bool) -> 'GPR':
+        """Noise variance to (1,L) [or (L,L)], kernel variance likewise, lengthscales to (L,M) or (L,1) (gpr/models.py:274-288)."""
+        target_shape = (self._L, self._L) if is_covariant else (1, self._L)
+        self._likelihood.data.frames.variance.broadcast_value(target_shape=target_shape, is_diagonal=True)
+        self._kernel.broadcast_parameters(variance_shape=target_shape, M=1 if is_isotropic else self._M)
+        self._implementation = None
+        self._implementation = self.implementation
+        return self
+
+
+class HipGP(GPR):
+    """Independent-output ARD-RBF GPs on one MI355X through librcgp.so.
+
+    One device handle holds X (shared by the L outputs) and the N x N work matrices; the outputs are fitted / queried in turn
+    (``rcgp_set_y``), exactly as the reference loops ``for gp in self._implementation`` (gpr/models.py:360-361). To spread
+    outputs or folds over GPUs, run one process per GPU and give each its share (``romcomma_amd.user.run``).
+    """
+
+    @classmethod
+    @property
+    def META(cls) -> Dict[str, Any]:
+        return {'maxiter': 5000, 'gtol': 1E-16}          # gpr/models.py:327-330
+
+    def __init__(self, name: str, fold: Fold, is_read: bool | None, is_covariant: bool, is_isotropic: bool,
+                 kernel_parameters: Kernel.Data | None = None, likelihood_variance: np.ndarray | None = None, device: int | None = None):
+        if is_covariant:
+            raise NotImplementedError('covariant (dependent-output) GPs are outside this backend: independent outputs only')
+        self._device = device
+        self._handle = None
+        self._cache: Dict[int, Dict[str, np.ndarray]] = {}
+        self._is_isotropic = bool(is_isotropic)
+        super().__init__(name, fold, is_read, is_covariant, is_isotropic, kernel_parameters, likelihood_variance)
+
+    # ---- device plumbing
+    @property
+    def device(self) -> int:
+        if self._device is None:
+            import os
+            self._device = int(os.environ.get('LOCAL_RANK', 0)) % max(_lib.device_count(), 1)
+        return self._device
+
+    @property
+    def handle(self) -> _lib.RcGP:
+        """The ``rcgp_handle`` (created on first use; X uploaded once)."""
+        if self._handle is None:
+            self._handle = _lib.RcGP(self._X, self._Y[:, 0], device=self.device)
+            self._active_output = 0
+        return self._handle
+
+    def close(self):
+        if self._handle is not None:
+            self._handle.close()
+            self._handle = None
+
+    def _hyper(self, l: int) -> Tuple[np.ndarray, float, float]:
+        record = self._kernel.implementation[l]
+        noise = max(float(self._likelihood.data.frames.variance.np[0, l]), Likelihood.VARIANCE_FLOOR)   # gpr/models.py:341
+        return np.broadcast_to(record['lengthscales'], (self._M,)).copy(), record['variance'], noise
+
+    def _select(self, l: int) -> _lib.RcGP:
+        """Make output ``l`` with its stored hyper-parameters current on the device. Re-sending identical values is skipped so
+        the cached Cholesky factor / L^-1 / alpha on the device survive between K_inv_Y, predict and Sobol calls."""
+        gp = self.handle
+        lengthscales, variance, noise = self._hyper(l)
+        signature = (l, tuple(lengthscales), variance, noise)
+        if getattr(self, '_device_signature', None) != signature:
+            if self._active_output != l:
+                gp.set_y(self._Y[:, l])
+                self._active_output = l
+            gp.set_hyper(lengthscales, variance, noise)
+            self._device_signature = signature
+        return gp
+
+    @property
+    def implementation(self) -> Tuple[Any, ...]:
+        """One (output index, hyper-parameter record) pair per independent output; the device handle is shared."""
+        if self._implementation is None:
+            self._cache = {}
+            self._implementation = tuple((l, record) for l, record in enumerate(self._kernel.implementation))
+        return self._implementation
+
+    # ---- the GPR contract
+    @property
+    def X(self) -> np.ndarray:
+        return self._X
+
+    @property
+    def Y(self) -> np.ndarray:
+        return self._Y
+
+    def calibrate(self, method: str = 'L-BFGS-B', **kwargs) -> Dict[str, Any]:
+        """Fit the hyper-parameters of every output by L-BFGS-B on -LML and persist them: likelihood/variance.csv,
+        likelihood/log_marginal.csv, kernel/variance.csv, kernel/lengthscales.csv and meta.json with the optimiser result
+        (gpr/models.py:345-373)."""
+        meta = self.read_meta() if self._meta_json.exists() else self.META
+        kernel_options = self._kernel.calibrate(**(meta.pop('kernel', {}) | kwargs.pop('kernel', {})))
+        likelihood_options = self._likelihood.calibrate(**(meta.pop('likelihood', {}) | kwargs.pop('likelihood', {})))
+        meta.update(kwargs)
+        meta.pop('result', None)
+        gp = self.handle
+        fits = []
+        for l in range(self._L):
+            lengthscales, variance, noise = self._hyper(l)
+            if self._active_output != l:
+                gp.set_y(self._Y[:, l])
+                self._active_output = l
+            self._device_signature = None
+            fits.append(fit_lbfgsb(gp, lengthscales[0] if self._is_isotropic else lengthscales, variance, noise,
+                                   is_isotropic=self._is_isotropic, train_lengthscales=bool(kernel_options['lengthscales']['variant']),
+                                   train_variance=bool(kernel_options['variance']), train_noise=bool(likelihood_options['variance']),
+                                   method=method, **meta))
+        meta.update({'result': str(tuple(fit['result'] for fit in fits)), 'kernel': kernel_options, 'likelihood': likelihood_options})
+        self.write_meta(meta)
+        self._likelihood.data.replace(variance=np.array([[fit['noise'] for fit in fits]]),
+                                      log_marginal=np.array([[fit['log_marginal'] for fit in fits]]))
+        n_ell = 1 if self._is_isotropic else self._M
+        self._kernel.data.replace(variance=np.array([[fit['variance'] for fit in fits]]),
+                                  lengthscales=np.stack([fit['lengthscales'][:n_ell] for fit in fits]))
+        self._kernel._implementation = None
+        self._implementation = None
+        self._implementation = self.implementation
+        return meta
+
+    def log_marginal_likelihood(self) -> np.ndarray:
+        """(L,) log marginal likelihood at the stored hyper-parameters."""
+        return np.array([self._select(l).lml() for l, _ in self.implementation])
+
+    def predict(self, X: np.ndarray, y_instead_of_f: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """(mean (o,L), SD (o,L)): predict_y when ``y_instead_of_f`` else predict_f (gpr/models.py:375-384)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        results = [self._select(l).predict(X, y_instead_of_f) for l, _ in self.implementation]
+        mean = np.stack([r[0] for r in results], axis=1)
+        sd = np.stack([r[1] for r in results], axis=1)
+        return np.atleast_2d(mean), np.atleast_2d(sd)
+
+    def predict_gradient(self, x: np.ndarray, y_instead_of_f: bool = True):
+        raise NotImplementedError('predict_gradient (gpr/models.py:386-415) is not on the accelerated path yet (SURVEY.md 8f rank 3)')
+
+    @property
+    def K_cho(self) -> np.ndarray:
+        """(L,N,N) lower Cholesky factors of K_l + noise_l I (gpr/models.py:427-439). Copies N^2 doubles per output to the
+        host: meant for inspection, the accelerated consumers use the device-resident factor."""
+        return np.stack([self._select(l).k_cho() for l, _ in self.implementation])
+
+    @property
+    def K_inv_Y(self) -> np.ndarray:
+        """(L,1,N): alpha_l = (K_l + noise_l I)^-1 y_l (gpr/models.py:441-444)."""
+        return np.stack([self._select(l).k_inv_y() for l, _ in self.implementation])[:, None, :]
+
+    def check_K_inv_Y(self, x: np.ndarray) -> np.ndarray:
+        """FOR TESTING: RMS over the o rows of k(x,X) . K_inv_Y - predict(x); ~0 (gpr/models.py:446-463)."""
+        predicted = self.predict(x)[0]
+        alpha = self.K_inv_Y[:, 0, :]
+        result = np.empty_like(predicted)
+        for l, record in self.implementation:
+            z = x / record['lengthscales']
+            Z = self._X / record['lengthscales']
+            r2 = np.sum(z * z, axis=1)[:, None] + np.sum(Z * Z, axis=1)[None, :] - 2.0 * z @ Z.T
+            result[:, l] = record['variance'] * np.exp(-0.5 * r2) @ alpha[l]
+        result -= predicted
+        return np.sqrt(np.sum(result * result, axis=0) / predicted.shape[0])
+
+
+MOGP = HipGP     #: the name the reference's run scripts import (gpr/models.py:324)

@@ -13,6 +13,7 @@ from typing import Any, Dict, Optional
 
 import numpy as np
 import scipy.optimize
+import scipy.special
 
 LIKELIHOOD_LOWER = 1.0e-6          # GPflow Gaussian likelihood: variance = 1e-6 + softplus(u)
 LIKELIHOOD_VARIANCE_FLOOR = 1.0001e-6     # reference gpr/models.py:62-65, :341
@@ -29,7 +30,7 @@ def inv_softplus(x):
 
 
 def sigmoid(u):
-    return 0.5 * (1.0 + np.tanh(0.5 * np.asarray(u, dtype=np.float64)))
+    return scipy.special.expit(np.asarray(u, dtype=np.float64))
 
 
 def fit_lbfgsb(gp, lengthscales, variance: float, noise: float, is_isotropic: bool = False, train_lengthscales: bool = True,

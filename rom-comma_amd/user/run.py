@@ -1,0 +1,140 @@
+"""Orchestration of GPR and GSA over the folds of a Repository (reference user/run.py:35-158), with the one structural
+change that suits 8 GPUs: the sequential ``for k in repo.folds`` loop (user/run.py:60-61,132-133) becomes a round-robin
+shard over the ranks of a ``torch.distributed`` job (one process per GPU). Folds are independent, so there is no data-path
+collective; ranks write their fold folders to the shared file system, meet at a barrier, and rank 0 runs the same
+``results.Collect`` pass the reference runs. Single-process use is unchanged.
+
+Naming, the isotropic -> anisotropic warm start by folder copy, per-fold Timer and ``ignore_exceptions`` follow the reference.
+"""
+from __future__ import annotations
+
+import shutil
+from pathlib import Path
+from typing import Any, List, Optional, Sequence
+
+import numpy as np
+
+from romcomma_amd import dist
+from romcomma_amd.data.storage import Fold, Repository
+from romcomma_amd.gpr.kernels import Kernel
+from romcomma_amd.gpr.models import GPR, MOGP
+from romcomma_amd.gsa.models import GSA, Sobol
+from romcomma_amd.user import contexts, results
+
+
+def _my_folds(repo: Repository) -> List[int]:
+    rank, world, _ = dist.env_rank_world()
+    folds = list(repo.folds)
+    return [folds[i] for i in dist.shard_units(len(folds), rank, world)] if dist.is_distributed() else folds
+
+
+def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | None, is_isotropic: bool | None,
+        ignore_exceptions: bool = False, kernel_parameters: Kernel.Data | None = None, likelihood_variance: np.ndarray | None = None,
+        is_calibrated: bool = True, is_tested: bool = True, **kwargs: Any) -> List[str]:
+    """GPR on a Fold, or across the Folds of a Repository (sharded over ranks when distributed).
+
+    ``is_read`` None = warm start from the nearest calibrated ancestor ('.i' before '.a'); ``is_isotropic`` None = run
+    isotropic then anisotropic; ``is_covariant`` must be False or None-resolved-to-False on this backend. Returns the model names.
+    """
+    if not isinstance(repo, Fold):
+        names: List[str] = []
+        for k in _my_folds(repo):
+            names = gpr(name, Fold(repo, k), is_read, is_covariant, is_isotropic, ignore_exceptions, kernel_parameters, likelihood_variance,
+                        is_calibrated, is_tested, **kwargs)
+        if dist.is_distributed():
+            dist.barrier()
+            if not names:                                   # a rank that owned no fold still needs the names for the return value
+                names = _names(name, is_covariant, is_isotropic)
+            if dist.env_rank_world()[0] != 0:
+                return names
+        if is_tested:
+            results.Collect({'test': {'header': [0, 1]}, 'test_summary': {'header': [0, 1], 'index_col': 0}}, {n: {} for n in names},
+                            ignore_exceptions).from_folds(repo, True)
+        results.Collect({'variance': {}, 'log_marginal': {}}, {f'{n}/likelihood': {} for n in names}, ignore_exceptions).from_folds(repo, True)
+        results.Collect({'variance': {}, 'lengthscales': {}}, {f'{n}/kernel': {} for n in names}, ignore_exceptions).from_folds(repo, True)
+        return names
+    if is_covariant is None:
+        is_covariant = False            # the reference would run independent then dependent (user/run.py:69-73); dependent GPs are out of scope
+    full_name = name + ('.c' if is_covariant else '.v')
+    if is_isotropic is None:
+        names = gpr(name, repo, is_read, is_covariant, True, ignore_exceptions, kernel_parameters, likelihood_variance, is_calibrated, is_tested, **kwargs)
+        return names + gpr(name, repo, None, is_covariant, False, ignore_exceptions, kernel_parameters, likelihood_variance, is_calibrated,
+                           is_tested, **kwargs)
+    full_name = full_name + ('.i' if is_isotropic else '.a')
+    if is_read is None:
+        if not (repo.folder / full_name).exists():
+            nearest_name = full_name[:-2] + '.i'
+            if not (repo.folder / nearest_name).exists():
+                return gpr(name, repo, False, is_covariant, is_isotropic, ignore_exceptions, kernel_parameters, likelihood_variance,
+                           is_calibrated, is_tested, **kwargs)
+            GPR.Data.copy(src_folder=repo.folder / nearest_name, dst_folder=repo.folder / full_name)
+        return gpr(name, repo, True, is_covariant, is_isotropic, ignore_exceptions, kernel_parameters, likelihood_variance, is_calibrated,
+                   is_tested, **kwargs)
+    with contexts.Timer(f'fold.{repo.meta["k"]} {full_name} GPR'):
+        gp = None
+        try:
+            if is_read:
+                gp = MOGP(full_name, repo, is_read, is_covariant, is_isotropic)
+            else:
+                gp = MOGP(full_name, repo, is_read, is_covariant, is_isotropic, kernel_parameters, likelihood_variance)
+            if is_calibrated:
+                gp.calibrate(**kwargs)
+            if is_tested:
+                gp.test()
+        except BaseException as exception:
+            if not ignore_exceptions:
+                raise exception
+        finally:
+            if gp is not None:
+                gp.close()
+    return [full_name]
+
+
+def _names(name: str, is_covariant: Optional[bool], is_isotropic: Optional[bool]) -> List[str]:
+    base = name + ('.c' if is_covariant else '.v')
+    return [base + '.i', base + '.a'] if is_isotropic is None else [base + ('.i' if is_isotropic else '.a')]
+
+
+def gsa(name: str, repo: Repository, is_covariant: Optional[bool], is_isotropic: Optional[bool],
+        kinds: GSA.Kind | Sequence[GSA.Kind] = GSA.ALL_KINDS, m: int = -1, ignore_exceptions: bool = False,
+        is_error_calculated: bool = False, **kwargs: Any) -> List[Path]:
+    """GSA on a Fold, or across the Folds of a Repository (sharded over ranks when distributed). Always resumes from the GP
+    stored by ``gpr`` (is_read=True, user/run.py:151). Returns the calculation folders relative to the fold."""
+    kinds = (kinds,) if isinstance(kinds, GSA.Kind) else kinds
+    if not isinstance(repo, Fold):
+        names: List[Path] = []
+        for k in _my_folds(repo):
+            names = gsa(name, Fold(repo, k), is_covariant, is_isotropic, kinds, m, ignore_exceptions, is_error_calculated, **kwargs)
+        if dist.is_distributed():
+            dist.barrier()
+            if dist.env_rank_world()[0] != 0:
+                return names
+            if not names:
+                return names
+        results.Collect({'S': {}, 'V': {}} | ({'T': {}, 'W': {}} if is_error_calculated else {}), {n: {} for n in names},
+                        ignore_exceptions).from_folds(repo, True)
+        for n in names:
+            shutil.copyfile(repo.fold_folder(repo.folds.start) / n / 'meta.json', repo.folder / n / 'meta.json')
+        return names
+    if is_covariant is None:
+        is_covariant = False
+    full_name = name + ('.c' if is_covariant else '.v')
+    if is_isotropic is None:
+        names = gsa(name, repo, is_covariant, True, kinds, m, ignore_exceptions, is_error_calculated, **kwargs)
+        return names + gsa(name, repo, is_covariant, False, kinds, m, ignore_exceptions, is_error_calculated, **kwargs)
+    full_name = full_name + ('.i' if is_isotropic else '.a')
+    names = []
+    with contexts.Timer(f'fold.{repo.meta["k"]} {full_name} GSA'):
+        gp = None
+        try:
+            gp = MOGP(full_name, repo, is_read=True, is_covariant=is_covariant, is_isotropic=is_isotropic)
+            for kind in kinds:
+                folder = Sobol(gp, kind, m, is_error_calculated, **kwargs).calibrate().get('folder')
+                names += [Path(folder).relative_to(repo.folder)]
+        except BaseException as exception:
+            if not ignore_exceptions:
+                raise exception
+        finally:
+            if gp is not None:
+                gp.close()
+    return names

@@ -1,0 +1,90 @@
+"""GPU end-to-end test of the drop-in surface: run.gpr + run.gsa on a small Repository (2 outputs, 2 folds), the reference's
+folder layout and file formats, and the in-memory results against the oracle at the fitted hyper-parameters."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import gp_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def make_repo(folder: Path, N=240, M=3, L=2, seed=0):
+    from romcomma_amd.data.storage import Repository
+    rng = np.random.default_rng(seed)
+    U = rng.random((N, M))
+    Y = np.stack([np.sin(2 * np.pi * U[:, 0]) + (0.5 + l) * U[:, 1] ** 2 + 0.1 * (1 - l) * U[:, 2] + 0.02 * rng.standard_normal(N)
+                  for l in range(L)], axis=1)
+    columns = pd.MultiIndex.from_tuples([('X', f'X.{m}') for m in range(M)] + [('Y', f'Y.{l}') for l in range(L)])
+    return Repository.from_df(folder, pd.DataFrame(np.concatenate([U, Y], axis=1), columns=columns))
+
+
+def test_run_gpr_gsa_end_to_end(gpu, tmp_path):
+    from romcomma_amd.data.storage import Fold
+    from romcomma_amd.gpr.models import MOGP
+    from romcomma_amd.gsa.models import GSA, Sobol
+    from romcomma_amd.user import run
+    repo = make_repo(tmp_path / 'repo').into_K_folds(-2, seed=3)
+    names = run.gpr('gpr', repo, is_read=False, is_covariant=False, is_isotropic=None)
+    assert names == ['gpr.v.i', 'gpr.v.a']
+    fold = Fold(repo, 0)
+    folder = fold.folder / 'gpr.v.a'
+    files = sorted(str(p.relative_to(folder)) for p in folder.rglob('*') if p.is_file())
+    assert files == ['kernel.csv', 'kernel/lengthscales.csv', 'kernel/variance.csv', 'likelihood/log_marginal.csv', 'likelihood/variance.csv',
+                     'meta.json', 'test.csv', 'test_summary.csv']
+    meta = json.loads((folder / 'meta.json').read_text())
+    assert meta['maxiter'] == 5000 and meta['gtol'] == 1e-16 and 'result' in meta and meta['kernel']['variance'] is True
+    assert (repo.folder / 'gpr.v.a' / 'test_summary.csv').exists() and (repo.folder / 'gpr.v.a' / 'kernel' / 'lengthscales.csv').exists()
+    iso = MOGP('gpr.v.i', fold, True, False, True)
+    assert iso.kernel.data.frames.lengthscales.np.shape == (2, 1)
+
+    gp = MOGP('gpr.v.a', fold, True, False, False)
+    ell = gp.kernel.data.frames.lengthscales.np
+    var = gp.kernel.data.frames.variance.np[0]
+    noise = gp.likelihood.data.frames.variance.np[0]
+    lml = gp.likelihood.data.frames.log_marginal.np[0]
+    X, Y = gp.X, gp.Y
+    assert ell.shape == (2, 3)
+    for l in range(2):
+        assert lml[l] == pytest.approx(o.lml(X, Y[:, l], ell[l], var[l], noise[l]), rel=1e-8)
+        # the optimum found on the GPU is a stationary point of the oracle's objective too
+        _, grad = o.lml_and_grad(X, Y[:, l], ell[l], var[l], noise[l])
+        assert np.max(np.abs(grad * np.concatenate([ell[l], [var[l], noise[l]]]))) < 2e-2 * abs(lml[l]) ** 0 * 5
+    assert np.max(gp.check_K_inv_Y(fold.test_x.values[:20])) < 1e-8
+    mean, sd = gp.predict(fold.test_x.values)
+    for l in range(2):
+        mr, sr = o.predict(X, Y[:, l], ell[l], var[l], noise[l], fold.test_x.values)
+        np.testing.assert_allclose(mean[:, l], mr, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(sd[:, l], sr, rtol=1e-7)
+    summary = pd.read_csv(folder / 'test_summary.csv', header=[0, 1], index_col=0)
+    rmse = np.sqrt(np.mean((fold.test_y.values - mean) ** 2, axis=0))
+    np.testing.assert_allclose(summary['RMSE'].values[0], rmse, rtol=1e-5)
+    assert np.all(rmse < 0.2)
+    gp.close()
+
+    gsa_names = run.gsa('gpr', repo, is_covariant=False, is_isotropic=False)
+    assert [str(n) for n in gsa_names] == ['gpr.v.a/gsa/first_order', 'gpr.v.a/gsa/closed', 'gpr.v.a/gsa/total']
+    S_csv = pd.read_csv(fold.folder / 'gpr.v.a' / 'gsa' / 'total' / 'S.csv', index_col=[0, 1])
+    assert list(S_csv.index.names) == ['l.0', 'l.1'] and list(S_csv.columns) == ['0', '1', '2', '3'] and S_csv.shape == (4, 4)
+    assert (repo.folder / 'gpr.v.a' / 'gsa' / 'closed' / 'S.csv').exists()
+
+    gp = MOGP('gpr.v.a', fold, True, False, False)
+    alpha = np.stack([o.k_inv_y(X, Y[:, l], ell[l], var[l], noise[l]) for l in range(2)])
+    ref = o.ClosedSobolOracle(X, alpha[:, None, :], var[None, :], ell)
+    for kind, okind in ((GSA.Kind.FIRST_ORDER, o.FIRST_ORDER), (GSA.Kind.CLOSED, o.CLOSED), (GSA.Kind.TOTAL, o.TOTAL)):
+        sobol = Sobol(gp, kind)
+        sobol.calibrate()
+        expect = o.gsa_calibrate(ref, okind, 3)
+        np.testing.assert_allclose(sobol.results['S'], expect['S'], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(sobol.results['V'], expect['V'], rtol=1e-6, atol=1e-9 * np.max(np.abs(expect['V'])))
+    stored = pd.read_csv(fold.folder / 'gpr.v.a' / 'gsa' / 'first_order' / 'S.csv', index_col=[0, 1]).values
+    np.testing.assert_allclose(stored, np.reshape(o.gsa_calibrate(ref, o.FIRST_ORDER, 3)['S'], (4, 4)), atol=6e-7)     # '%.6f'
+    first = Sobol(gp, GSA.Kind.FIRST_ORDER, m=1)
+    first.calibrate()
+    assert first.results['S'].shape == (2, 2, 2) and first.folder.name == 'first_order.1'
+    with pytest.raises(NotImplementedError):
+        Sobol(gp, GSA.Kind.CLOSED, is_error_calculated=True).calibrate()
+    gp.close()
