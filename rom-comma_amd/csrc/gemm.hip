@@ -19,35 +19,50 @@
 #define SLAB 2304       // doubles per operand slab (both layouts)
 #define GEMM_LDS (4 * SLAB)
 
-struct Regs4 { double2 v[4]; };
+// WN = number of wave columns of the workgroup: 2 -> 256 threads, waves 2x2, 64x64 per wave (4x4 MFMA tiles);
+//                                                4 -> 512 threads, waves 2x4, 64x32 per wave (4x2 MFMA tiles).
+// The 512-thread shape keeps a wave under 128 registers, so two workgroups fit a CU = 4 waves per SIMD: the fp64 MFMA
+// pipe sustains 36 TFLOP/s with one wave per SIMD, 46 with two and 48-49 with four (tools/mfma_peak.hip).
+#ifndef RC_WN
+#define RC_WN 4
+#endif
+template <int WN> struct Geo {
+  static constexpr int NT = 128 * WN;          // threads
+  static constexpr int NI = 8 / WN;            // MFMA tile columns per wave (wave tile = 64 x 16*NI)
+  static constexpr int NP = 1024 / NT;         // double2 loads per thread per operand slab
+};
 
-template <bool KC>
-__device__ __forceinline__ void slab_load(const double* __restrict__ src, int64_t ld, int64_t r0, int64_t k0, Regs4& rg) {
+template <int WN> struct RegsN { double2 v[Geo<WN>::NP]; };
+
+template <bool KC, int WN>
+__device__ __forceinline__ void slab_load(const double* __restrict__ src, int64_t ld, int64_t r0, int64_t k0, RegsN<WN>& rg) {
   const int t = threadIdx.x;
+  constexpr int NT = Geo<WN>::NT, NP = Geo<WN>::NP;
   if (KC) {
     const int kk = (t & 7) * 2, r = t >> 3;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      rg.v[p] = *reinterpret_cast<const double2*>(src + (r0 + r + 32 * p) * ld + k0 + kk);
+    for (int p = 0; p < NP; ++p)
+      rg.v[p] = *reinterpret_cast<const double2*>(src + (r0 + r + (NT / 8) * p) * ld + k0 + kk);
   } else {
     const int r = (t & 63) * 2, k = t >> 6;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      rg.v[p] = *reinterpret_cast<const double2*>(src + (k0 + k + 4 * p) * ld + r0 + r);
+    for (int p = 0; p < NP; ++p)
+      rg.v[p] = *reinterpret_cast<const double2*>(src + (k0 + k + (NT / 64) * p) * ld + r0 + r);
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void slab_store(double* lds, const Regs4& rg) {
+template <bool KC, int WN>
+__device__ __forceinline__ void slab_store(double* lds, const RegsN<WN>& rg) {
   const int t = threadIdx.x;
+  constexpr int NT = Geo<WN>::NT, NP = Geo<WN>::NP;
   if (KC) {
     const int kk = (t & 7) * 2, r = t >> 3;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<double2*>(lds + (r + 32 * p) * LDK + kk) = rg.v[p];
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<double2*>(lds + (r + (NT / 8) * p) * LDK + kk) = rg.v[p];
   } else {
     const int r = (t & 63) * 2, k = t >> 6;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<double2*>(lds + (k + 4 * p) * LDR + r) = rg.v[p];
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<double2*>(lds + (k + (NT / 64) * p) * LDR + r) = rg.v[p];
   }
 }
 
@@ -56,67 +71,74 @@ __device__ __forceinline__ double frag_read(const double* lds, int row, int k) {
   return KC ? lds[row * LDK + k] : lds[k * LDR + row];
 }
 
-// acc += A(i, k0:k1) * B(j, k0:k1)^T for the 128x128 tile (i from a0, j from b0). k0,k1 multiples of 16, k1 > k0.
-template <bool AKC, bool BKC>
+// acc (+/-)= A(i, k0:k1) * B(j, k0:k1)^T for the 128x128 tile (i from a0, j from b0). k0,k1 multiples of 16, k1 > k0.
+// NEG = true subtracts the product (the A fragment is negated), so that an update kernel can start from acc = C.
+template <bool AKC, bool BKC, int WN, bool NEG = false>
 __device__ __forceinline__ void gemm_mainloop(const double* __restrict__ A, int64_t lda, int64_t a0, const double* __restrict__ B,
-                                              int64_t ldb, int64_t b0, int64_t k0, int64_t k1, v4d (&acc)[4][4], double* lds) {
+                                              int64_t ldb, int64_t b0, int64_t k0, int64_t k1, v4d (&acc)[4][Geo<WN>::NI], double* lds) {
+  constexpr int NI = Geo<WN>::NI;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  const int wr = (wave / WN) * 64, wc = (wave % WN) * (16 * NI);
   const int fr = lane & 15, fq = lane >> 4;
   const int nk = (int)((k1 - k0) >> 4);
-  Regs4 ra, rb;
-  slab_load<AKC>(A, lda, a0, k0, ra);
-  slab_load<BKC>(B, ldb, b0, k0, rb);
-  slab_store<AKC>(lds, ra);
-  slab_store<BKC>(lds + SLAB, rb);
+  RegsN<WN> ra, rb;
+  slab_load<AKC, WN>(A, lda, a0, k0, ra);
+  slab_load<BKC, WN>(B, ldb, b0, k0, rb);
+  slab_store<AKC, WN>(lds, ra);
+  slab_store<BKC, WN>(lds + SLAB, rb);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const double* la = lds + (kt & 1) * 2 * SLAB;
     const double* lb = la + SLAB;
-    if (kt + 1 < nk) {
-      slab_load<AKC>(A, lda, a0, k0 + (int64_t)(kt + 1) * 16, ra);
-      slab_load<BKC>(B, ldb, b0, k0 + (int64_t)(kt + 1) * 16, rb);
-    }
+    // Branch-free prefetch: the last iteration re-reads its own slab (an L2 hit) and parks it in the idle LDS stage, so the
+    // staging registers never become conditionally live (hipcc otherwise keeps them in scratch memory).
+    const int64_t kn = k0 + (int64_t)((kt + 1 < nk) ? kt + 1 : kt) * 16;
+    slab_load<AKC, WN>(A, lda, a0, kn, ra);
+    slab_load<BKC, WN>(B, ldb, b0, kn, rb);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      double af[4], bf[4];
+      double af[4], bf[NI];
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        af[x] = frag_read<AKC>(la, wr + 16 * x + fr, 4 * s + fq);
-        bf[x] = frag_read<BKC>(lb, wc + 16 * x + fr, 4 * s + fq);
+        const double v = frag_read<AKC>(la, wr + 16 * x + fr, 4 * s + fq);
+        af[x] = NEG ? -v : v;
       }
+#pragma unroll
+      for (int x = 0; x < NI; ++x) bf[x] = frag_read<BKC>(lb, wc + 16 * x + fr, 4 * s + fq);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
-      double* na = lds + ((kt + 1) & 1) * 2 * SLAB;
-      slab_store<AKC>(na, ra);
-      slab_store<BKC>(na + SLAB, rb);
-    }
+    double* na = lds + ((kt + 1) & 1) * 2 * SLAB;
+    slab_store<AKC, WN>(na, ra);
+    slab_store<BKC, WN>(na + SLAB, rb);
     __syncthreads();
   }
 }
 
-__device__ __forceinline__ void acc_zero(v4d (&acc)[4][4]) {
+template <int NI>
+__device__ __forceinline__ void acc_zero(v4d (&acc)[4][NI]) {
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (v4d){0.0, 0.0, 0.0, 0.0};
 }
 
 // Visit every accumulator element with its (row, col) inside the 128x128 tile.
 #define RC_FOR_ACC(mi, ni, r, row, col)                                  \
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                       \
-  _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                       \
+  _Pragma("unroll") for (int ni = 0; ni < NI_; ++ni)                     \
   _Pragma("unroll") for (int r = 0; r < 4; ++r)                          \
     for (int row = wr_ + 16 * mi + 4 * r + fq_, col = wc_ + 16 * ni + fr_, once_ = 1; once_; once_ = 0)
 
-#define RC_LANE_VARS                                                     \
-  const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;          \
-  const int wr_ = (wave_ >> 1) * 64, wc_ = (wave_ & 1) * 64;             \
+#define RC_LANE_VARS(WN)                                                          \
+  constexpr int NI_ = Geo<WN>::NI;                                                \
+  const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;                   \
+  const int wr_ = (wave_ / WN) * 64, wc_ = (wave_ % WN) * (16 * NI_);             \
   const int fr_ = lane_ & 15, fq_ = lane_ >> 4;
+
+#define RC_BOUNDS(WN) __launch_bounds__(128 * WN, WN)
 
 __device__ __forceinline__ void tri_decode(int64_t id, int& ti, int& tj) {
   int t = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
@@ -126,27 +148,41 @@ __device__ __forceinline__ void tri_decode(int64_t id, int& ti, int& tj) {
   tj = (int)(id - (int64_t)t * (t + 1) / 2);
 }
 
+// acc = C tile (the MFMA C/D layout), for kernels that update C in place
+template <int WN>
+__device__ __forceinline__ void acc_load(v4d (&acc)[4][Geo<WN>::NI], const double* __restrict__ Ct, int64_t ldc) {
+  RC_LANE_VARS(WN)
+  RC_FOR_ACC(mi, ni, r, row, col) { acc[mi][ni][r] = Ct[(int64_t)row * ldc + col]; }
+}
+
+template <int WN>
+__device__ __forceinline__ void acc_store(const v4d (&acc)[4][Geo<WN>::NI], double* __restrict__ Ct, int64_t ldc) {
+  RC_LANE_VARS(WN)
+  RC_FOR_ACC(mi, ni, r, row, col) { Ct[(int64_t)row * ldc + col] = acc[mi][ni][r]; }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // C[i][j] -= sum_k P[i][k] P[j][k] on the lower tiles of an n x n matrix (trailing update of the blocked Cholesky).
+// The accumulators start from the C tile (its loads overlap the first operand slabs) and the product is subtracted in
+// the MFMA chain, so the epilogue is stores only.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_syrk_lower(double* __restrict__ C, int64_t ldc, const double* __restrict__ P, int64_t ldp,
-                                                    int kk) {
+template <int WN>
+__global__ void RC_BOUNDS(WN) k_syrk_lower(double* __restrict__ C, int64_t ldc, const double* __restrict__ P, int64_t ldp, int kk) {
   __shared__ double lds[GEMM_LDS];
   int ti, tj;
   tri_decode(blockIdx.x, ti, tj);
-  v4d acc[4][4];
-  acc_zero(acc);
-  gemm_mainloop<true, true>(P, ldp, (int64_t)ti * 128, P, ldp, (int64_t)tj * 128, 0, kk, acc, lds);
-  RC_LANE_VARS
+  v4d acc[4][Geo<WN>::NI];
   double* Ct = C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128;
-  RC_FOR_ACC(mi, ni, r, row, col) { Ct[(int64_t)row * ldc + col] -= acc[mi][ni][r]; }
+  acc_load<WN>(acc, Ct, ldc);
+  gemm_mainloop<true, true, WN, true>(P, ldp, (int64_t)ti * 128, P, ldp, (int64_t)tj * 128, 0, kk, acc, lds);
+  acc_store<WN>(acc, Ct, ldc);
 }
 
 int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk) {
   const int64_t T = n / 128;
   if (T <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, (double)n * (double)(n + 128) * (double)kk);   // 2*kk flops per lower-tile element
-  hipLaunchKernelGGL(k_syrk_lower, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, h->stream, C, ldc, P, ldp, (int)kk);
+  hipLaunchKernelGGL(k_syrk_lower<RC_WN>, dim3((unsigned)(T * (T + 1) / 2)), dim3(128 * RC_WN), 0, h->stream, C, ldc, P, ldp, (int)kk);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -154,25 +190,25 @@ int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double*
 // ---------------------------------------------------------------------------------------------------------------------
 // C (m x n) -= A (m x kk) * B (n x kk)^T, skipping tiles strictly above the global diagonal.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_gemm_nt_sub(double* __restrict__ C, int64_t ldc, const double* __restrict__ A, int64_t lda,
-                                                     const double* __restrict__ B, int64_t ldb, int kk, int64_t row0, int64_t col0) {
+template <int WN>
+__global__ void RC_BOUNDS(WN) k_gemm_nt_sub(double* __restrict__ C, int64_t ldc, const double* __restrict__ A, int64_t lda,
+                                            const double* __restrict__ B, int64_t ldb, int kk, int64_t row0, int64_t col0) {
   __shared__ double lds[GEMM_LDS];
   const int tj = blockIdx.x, ti = blockIdx.y;
   if (col0 + (int64_t)tj * 128 > row0 + (int64_t)ti * 128) return;
-  v4d acc[4][4];
-  acc_zero(acc);
-  gemm_mainloop<true, true>(A, lda, (int64_t)ti * 128, B, ldb, (int64_t)tj * 128, 0, kk, acc, lds);
-  RC_LANE_VARS
+  v4d acc[4][Geo<WN>::NI];
   double* Ct = C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128;
-  RC_FOR_ACC(mi, ni, r, row, col) { Ct[(int64_t)row * ldc + col] -= acc[mi][ni][r]; }
+  acc_load<WN>(acc, Ct, ldc);
+  gemm_mainloop<true, true, WN, true>(A, lda, (int64_t)ti * 128, B, ldb, (int64_t)tj * 128, 0, kk, acc, lds);
+  acc_store<WN>(acc, Ct, ldc);
 }
 
 int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0) {
   if (m <= 0 || n <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)m * (double)n * (double)kk);
-  hipLaunchKernelGGL(k_gemm_nt_sub, dim3((unsigned)(n / 128), (unsigned)(m / 128)), dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb,
-                     (int)kk, row0, col0);
+  hipLaunchKernelGGL(k_gemm_nt_sub<RC_WN>, dim3((unsigned)(n / 128), (unsigned)(m / 128)), dim3(128 * RC_WN), 0, h->stream, C, ldc, A, lda,
+                     B, ldb, (int)kk, row0, col0);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -181,20 +217,20 @@ int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double
 // Panel triangular solve as a GEMM with the explicit inverse of the diagonal block: P <- P * invL^T (in place), and the
 // fused forward substitution of the right-hand side: rhs[rows] -= P_new * wj.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_trsm_panel(double* __restrict__ P, int64_t ldp, const double* __restrict__ invL,
-                                                    double* __restrict__ rhs, const double* __restrict__ wj) {
+template <int WN>
+__global__ void RC_BOUNDS(WN) k_trsm_panel(double* __restrict__ P, int64_t ldp, const double* __restrict__ invL, double* __restrict__ rhs,
+                                           const double* __restrict__ wj) {
   __shared__ double lds[GEMM_LDS];
-  __shared__ double rowsum[128];
+  __shared__ double rowsum[WN][128];
   const int ti = blockIdx.x;
-  v4d acc[4][4];
+  v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
-  if (threadIdx.x < 128) rowsum[threadIdx.x] = 0.0;
-  gemm_mainloop<true, true>(P, ldp, (int64_t)ti * 128, invL, 128, 0, 0, 128, acc, lds);
-  RC_LANE_VARS
+  gemm_mainloop<true, true, WN>(P, ldp, (int64_t)ti * 128, invL, 128, 0, 0, 128, acc, lds);
+  RC_LANE_VARS(WN)
   double* Pt = P + (int64_t)ti * 128 * ldp;
-  double wv[4];
+  double wv[NI_];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) wv[ni] = wj[wc_ + 16 * ni + fr_];
+  for (int ni = 0; ni < NI_; ++ni) wv[ni] = wj[wc_ + 16 * ni + fr_];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -202,7 +238,7 @@ __global__ void __launch_bounds__(256) k_trsm_panel(double* __restrict__ P, int6
       const int row = wr_ + 16 * mi + 4 * r + fq_;
       double s = 0.0;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+      for (int ni = 0; ni < NI_; ++ni) {
         const double v = acc[mi][ni][r];
         Pt[(int64_t)row * ldp + wc_ + 16 * ni + fr_] = v;
         s += v * wv[ni];
@@ -211,16 +247,21 @@ __global__ void __launch_bounds__(256) k_trsm_panel(double* __restrict__ P, int6
       s += __shfl_xor(s, 2);
       s += __shfl_xor(s, 4);
       s += __shfl_xor(s, 8);
-      if (fr_ == 0) atomicAdd(&rowsum[row], s);      // exactly two addends per row (the two column waves): order-independent
+      if (fr_ == 0) rowsum[wave_ % WN][row] = s;            // one slot per column-wave: summed in a fixed order below
     }
   __syncthreads();
-  if (threadIdx.x < 128) rhs[(int64_t)ti * 128 + threadIdx.x] -= rowsum[threadIdx.x];
+  if (threadIdx.x < 128) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < WN; ++c) s += rowsum[c][threadIdx.x];
+    rhs[(int64_t)ti * 128 + threadIdx.x] -= s;
+  }
 }
 
 int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double* invL, int64_t m, double* rhs, const double* wj) {
   if (m <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, (double)m * 128.0 * 128.0);     // triangular: m*128*128 flops algorithmic
-  hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)(m / 128)), dim3(256), 0, h->stream, P, ldp, invL, rhs, wj);
+  hipLaunchKernelGGL(k_trsm_panel<RC_WN>, dim3((unsigned)(m / 128)), dim3(128 * RC_WN), 0, h->stream, P, ldp, invL, rhs, wj);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -229,36 +270,33 @@ int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double*
 // Triangular inverse by recursive doubling. With L = [[A,0],[B,C]]: L^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]].
 // Level s: for each pair p (colA = 2ps, rowC = colA + s):  T = B * A^-1 -> S ; X21 = -C^-1 * T -> W.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_trtri_T(const double* __restrict__ Lm, const double* __restrict__ W, double* __restrict__ S,
-                                                 int64_t ld, int64_t Np, int64_t s) {
+template <int WN>
+__global__ void RC_BOUNDS(WN) k_trtri_T(const double* __restrict__ Lm, const double* __restrict__ W, double* __restrict__ S, int64_t ld,
+                                        int64_t Np, int64_t s) {
   __shared__ double lds[GEMM_LDS];
   const int tj = blockIdx.x, ti = blockIdx.y;
   const int64_t colA = 2 * s * (int64_t)blockIdx.z, rowC = colA + s;
   if (rowC + (int64_t)ti * 128 >= Np) return;
-  v4d acc[4][4];
+  v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
   // A operand: B block of L, element (i,k) at Lm[(rowC+i)*ld + colA + k]; B operand: A^-1 element (k,j) at W[(colA+k)*ld + colA + j]
-  gemm_mainloop<true, false>(Lm + rowC * ld + colA, ld, (int64_t)ti * 128, W + colA * ld + colA, ld, (int64_t)tj * 128,
-                             (int64_t)tj * 128, s, acc, lds);
-  RC_LANE_VARS
-  double* St = S + (rowC + (int64_t)ti * 128) * ld + colA + (int64_t)tj * 128;
-  RC_FOR_ACC(mi, ni, r, row, col) { St[(int64_t)row * ld + col] = acc[mi][ni][r]; }
+  gemm_mainloop<true, false, WN>(Lm + rowC * ld + colA, ld, (int64_t)ti * 128, W + colA * ld + colA, ld, (int64_t)tj * 128,
+                                 (int64_t)tj * 128, s, acc, lds);
+  acc_store<WN>(acc, S + (rowC + (int64_t)ti * 128) * ld + colA + (int64_t)tj * 128, ld);
 }
 
-__global__ void __launch_bounds__(256) k_trtri_X(double* __restrict__ W, const double* __restrict__ S, int64_t ld, int64_t Np,
-                                                 int64_t s) {
+template <int WN>
+__global__ void RC_BOUNDS(WN) k_trtri_X(double* __restrict__ W, const double* __restrict__ S, int64_t ld, int64_t Np, int64_t s) {
   __shared__ double lds[GEMM_LDS];
   const int tj = blockIdx.x, ti = blockIdx.y;
   const int64_t colA = 2 * s * (int64_t)blockIdx.z, rowC = colA + s;
   if (rowC + (int64_t)ti * 128 >= Np) return;
-  v4d acc[4][4];
+  v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
   // A operand: C^-1 element (i,k) at W[(rowC+i)*ld + rowC + k], zero for k > i; B operand: T element (k,j) at S[(rowC+k)*ld + colA + j]
-  gemm_mainloop<true, false>(W + rowC * ld + rowC, ld, (int64_t)ti * 128, S + rowC * ld + colA, ld, (int64_t)tj * 128, 0,
-                             (int64_t)(ti + 1) * 128, acc, lds);
-  RC_LANE_VARS
-  double* Wt = W + (rowC + (int64_t)ti * 128) * ld + colA + (int64_t)tj * 128;
-  RC_FOR_ACC(mi, ni, r, row, col) { Wt[(int64_t)row * ld + col] = -acc[mi][ni][r]; }
+  gemm_mainloop<true, false, WN, true>(W + rowC * ld + rowC, ld, (int64_t)ti * 128, S + rowC * ld + colA, ld, (int64_t)tj * 128, 0,
+                                       (int64_t)(ti + 1) * 128, acc, lds);
+  acc_store<WN>(acc, W + (rowC + (int64_t)ti * 128) * ld + colA + (int64_t)tj * 128, ld);
 }
 
 int rc_launch_trtri_level(rcgp_handle_s* h, int64_t s) {
@@ -272,13 +310,14 @@ int rc_launch_trtri_level(rcgp_handle_s* h, int64_t s) {
   if (npairs == 0) return 0;
   {
     RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)s * (double)s * (double)s);
-    hipLaunchKernelGGL(k_trtri_T, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(256), 0, h->stream, h->A, h->Linv, h->S, Np,
-                       Np, s);
+    hipLaunchKernelGGL(k_trtri_T<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->stream, h->A, h->Linv,
+                       h->S, Np, Np, s);
     RC_HIP(hipGetLastError());
   }
   {
     RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)s * (double)s * (double)s);
-    hipLaunchKernelGGL(k_trtri_X, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(256), 0, h->stream, h->Linv, h->S, Np, Np, s);
+    hipLaunchKernelGGL(k_trtri_X<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->stream, h->Linv, h->S,
+                       Np, Np, s);
     RC_HIP(hipGetLastError());
   }
   return 0;
@@ -289,31 +328,32 @@ int rc_launch_trtri_level(rcgp_handle_s* h, int64_t s) {
 //   Wij = alpha_i alpha_j - Kinv_ij ; G_m = sum Wij Kij (z_im - z_jm)^2 ; G_var = sum Wij Kij ; G_noise = tr W
 // K^-1 is never written: each lower tile is reduced in the epilogue to M+2 partial sums (row blockIdx of h->partial).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int LZ>
-__global__ void __launch_bounds__(256) k_grad(const double* __restrict__ Linv, int64_t ld, int64_t Np, int64_t N, int M,
-                                              const double* __restrict__ Z, const double* __restrict__ sq,
-                                              const double* __restrict__ alpha, double var, double* __restrict__ partial) {
+template <int LZ, int WN>
+__global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld, int64_t Np, int64_t N, int M, const double* __restrict__ Z,
+                                     const double* __restrict__ sq, const double* __restrict__ alpha, double var,
+                                     double* __restrict__ partial) {
   constexpr int ZL = 2 * 128 * LZ;
-  __shared__ double lds[(GEMM_LDS > ZL ? GEMM_LDS : ZL) + 4 * (RC_MAX_M + 2)];
+  constexpr int NW = 2 * WN;                                  // waves per workgroup
+  __shared__ double lds[(GEMM_LDS > ZL ? GEMM_LDS : ZL) + NW * (RC_MAX_M + 2)];
   int ti, tj;
   tri_decode(blockIdx.x, ti, tj);
-  v4d acc[4][4];
+  v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
-  gemm_mainloop<false, false>(Linv, ld, (int64_t)ti * 128, Linv, ld, (int64_t)tj * 128, (int64_t)ti * 128, Np, acc, lds);
-  RC_LANE_VARS
+  gemm_mainloop<false, false, WN>(Linv, ld, (int64_t)ti * 128, Linv, ld, (int64_t)tj * 128, (int64_t)ti * 128, Np, acc, lds);
+  RC_LANE_VARS(WN)
   double* zi = lds;
   double* zj = lds + 128 * LZ;
   double* red = lds + (GEMM_LDS > ZL ? GEMM_LDS : ZL);
-  for (int e = threadIdx.x; e < 128 * M; e += 256) {
+  for (int e = threadIdx.x; e < 128 * M; e += 128 * WN) {
     const int rr = e / M, m = e - rr * M;
     zi[rr * LZ + m] = Z[((int64_t)ti * 128 + rr) * M + m];
     zj[rr * LZ + m] = Z[((int64_t)tj * 128 + rr) * M + m];
   }
   __syncthreads();
   double gvar = 0.0, gnoise = 0.0;
-  double aj[4], sj[4];
+  double aj[NI_], sj[NI_];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
+  for (int ni = 0; ni < NI_; ++ni) {
     const int64_t j = (int64_t)tj * 128 + wc_ + 16 * ni + fr_;
     aj[ni] = alpha[j];
     sj[ni] = sq[j];
@@ -326,7 +366,7 @@ __global__ void __launch_bounds__(256) k_grad(const double* __restrict__ Linv, i
       const int64_t i = (int64_t)ti * 128 + row;
       const double ai = alpha[i], si = sq[i];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+      for (int ni = 0; ni < NI_; ++ni) {
         const int col = wc_ + 16 * ni + fr_;
         const int64_t j = (int64_t)tj * 128 + col;
         double dot = 0.0;
@@ -341,7 +381,6 @@ __global__ void __launch_bounds__(256) k_grad(const double* __restrict__ Linv, i
         if (valid && j == i) gnoise += wij;
       }
     }
-  // block reduction helper: wave shuffle then 4 waves through LDS
   auto wave_sum = [](double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -355,7 +394,7 @@ __global__ void __launch_bounds__(256) k_grad(const double* __restrict__ Linv, i
       for (int r = 0; r < 4; ++r) {
         const double zim = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI_; ++ni) {
           const double d = zim - zj[(wc_ + 16 * ni + fr_) * LZ + m];
           g = fma(acc[mi][ni][r], d * d, g);
         }
@@ -372,8 +411,10 @@ __global__ void __launch_bounds__(256) k_grad(const double* __restrict__ Linv, i
   __syncthreads();
   if (threadIdx.x < M + 2) {
     const int m = threadIdx.x;
-    partial[(int64_t)blockIdx.x * (M + 2) + m] =
-        (red[m] + red[(RC_MAX_M + 2) + m]) + (red[2 * (RC_MAX_M + 2) + m] + red[3 * (RC_MAX_M + 2) + m]);
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * (RC_MAX_M + 2) + m];      // fixed order: bit-reproducible
+    partial[(int64_t)blockIdx.x * (M + 2) + m] = s;
   }
 }
 
@@ -385,11 +426,11 @@ int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
   const double np = (double)h->Np;
   RcProfScope ps(h, RC_K_GEMM, np * np * np / 3.0);
   if (h->M <= 32)
-    hipLaunchKernelGGL(k_grad<33>, dim3((unsigned)nb), dim3(256), 0, h->stream, h->Linv, h->Np, h->Np, h->N, h->M, h->Z, h->sq, h->alpha,
-                       h->var, h->partial);
+    hipLaunchKernelGGL((k_grad<33, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->stream, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
+                       h->sq, h->alpha, h->var, h->partial);
   else
-    hipLaunchKernelGGL(k_grad<65>, dim3((unsigned)nb), dim3(256), 0, h->stream, h->Linv, h->Np, h->Np, h->N, h->M, h->Z, h->sq, h->alpha,
-                       h->var, h->partial);
+    hipLaunchKernelGGL((k_grad<65, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->stream, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
+                       h->sq, h->alpha, h->var, h->partial);
   RC_HIP(hipGetLastError());
   *nrows = (int)nb;
   return 0;
@@ -399,18 +440,19 @@ int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
 // Predictive variance term: colsum((L^-1 K*)^2). A = Linv (Np x Np, lower) times KsT^T (KsT is np x Np, one test point
 // per row). The product is never written: each tile is squared and column-summed into partial[ti][j].
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_predict_var(const double* __restrict__ Linv, int64_t ld, const double* __restrict__ KsT,
-                                                     int64_t ldk, int64_t np, double* __restrict__ partial) {
+template <int WN>
+__global__ void RC_BOUNDS(WN) k_predict_var(const double* __restrict__ Linv, int64_t ld, const double* __restrict__ KsT, int64_t ldk,
+                                            int64_t np, double* __restrict__ partial) {
   __shared__ double lds[GEMM_LDS];
   __shared__ double colsum[2][128];
   const int tj = blockIdx.x;
   const int ti = gridDim.y - 1 - blockIdx.y;          // heavy row tiles first
-  v4d acc[4][4];
+  v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
-  gemm_mainloop<true, true>(Linv, ld, (int64_t)ti * 128, KsT, ldk, (int64_t)tj * 128, 0, (int64_t)(ti + 1) * 128, acc, lds);
-  RC_LANE_VARS
+  gemm_mainloop<true, true, WN>(Linv, ld, (int64_t)ti * 128, KsT, ldk, (int64_t)tj * 128, 0, (int64_t)(ti + 1) * 128, acc, lds);
+  RC_LANE_VARS(WN)
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
+  for (int ni = 0; ni < NI_; ++ni) {
     double s = 0.0;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -418,7 +460,7 @@ __global__ void __launch_bounds__(256) k_predict_var(const double* __restrict__ 
       for (int r = 0; r < 4; ++r) s = fma(acc[mi][ni][r], acc[mi][ni][r], s);
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    if (fq_ == 0) colsum[wave_ >> 1][wc_ + 16 * ni + fr_] = s;
+    if (fq_ == 0) colsum[wave_ / WN][wc_ + 16 * ni + fr_] = s;
   }
   __syncthreads();
   if (threadIdx.x < 128)
@@ -439,8 +481,8 @@ int rc_launch_predict_var(rcgp_handle_s* h, int64_t np) {
   if (rc) return rc;
   {
     RcProfScope ps(h, RC_K_GEMM, (double)h->Np * (double)h->Np * (double)np);
-    hipLaunchKernelGGL(k_predict_var, dim3((unsigned)(np / 128), (unsigned)T), dim3(256), 0, h->stream, h->Linv, h->Np, h->KsT, h->Np,
-                       np, h->partial);
+    hipLaunchKernelGGL(k_predict_var<RC_WN>, dim3((unsigned)(np / 128), (unsigned)T), dim3(128 * RC_WN), 0, h->stream, h->Linv, h->Np, h->KsT,
+                       h->Np, np, h->partial);
     RC_HIP(hipGetLastError());
   }
   {
@@ -450,4 +492,3 @@ int rc_launch_predict_var(rcgp_handle_s* h, int64_t np) {
   }
   return 0;
 }
-
