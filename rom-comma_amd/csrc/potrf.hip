@@ -3,13 +3,11 @@
 // (reference call sites gpr/models.py:360, 427-439).
 //
 // Two-level blocking: outer panels of RC_NB_OUTER columns (K of the big MFMA trailing update), inner blocks of 128:
-//   k_diag       : one workgroup factors the 128x128 diagonal block in LDS, inverts it, emits w_j and log L_ii
+//   k_diag       : one workgroup factors the 128x128 diagonal block in registers, inverts it, emits w_j and log L_ii
 //   k_trsm_panel : rows below <- rows below * inv(L_jj)^T  (a GEMM, gemm.hip), rhs update fused
 //   k_gemm_nt_sub: update of the remaining columns of the current outer panel (K = 128)
 //   k_syrk_lower : trailing update with the whole outer panel (K = RC_NB_OUTER)
 #include "common.h"
-
-#define DS 129   // LDS row stride (doubles) of the diagonal block
 
 // Newton-refined reciprocal square root (v_rsq_f64 seed): relative error ~1 ulp.
 __device__ __forceinline__ double rc_rsqrt(double d) {
@@ -19,20 +17,22 @@ __device__ __forceinline__ double rc_rsqrt(double d) {
   return y;
 }
 
-// The 128x128 block is distributed over the 256 threads' registers, 8x8 elements per thread in a 16-cyclic layout
-// (thread (tx, ty) owns rows ty + 16a, columns tx + 16b), so the rank-1 update of a column step is 64 independent
-// register FMAs and the only communication per step is one 128-entry column through LDS and ONE barrier.
-// KB (the 16-column group of the pivot) is a template parameter so that every register index is static.
+// The 128x128 block is distributed over the registers of 512 threads: thread (tx = t & 15, ty = t >> 4) owns rows
+// ty + 32a (a < 4) and columns tx + 16b (b < 8). Both L and the working copy of X = L^-1 live in registers (32 doubles each), so
+// the kernel needs only ~6 KB of LDS and can share a CU with a trailing-update workgroup (look-ahead). Per pivot the only
+// communication is one 128-entry column (and, for the inverse, one row) through LDS and ONE barrier.
+// KB = k >> 4 is a template parameter so that every register index is static; blocks strictly above the diagonal
+// (b >= 2a + 2) are never touched.
 template <int KB>
-__device__ __forceinline__ void chol_steps(double (&R)[8][8], double* colbuf, double* rsd, double* diag, int* info, int64_t j0,
-                                           const int tx, const int ty) {
+__device__ __forceinline__ void chol_steps(double (&Lr)[4][8], double* colbuf, double* rsd, int* info, int64_t j0, const int tx,
+                                           const int ty) {
 #pragma unroll 1
   for (int kx = 0; kx < 16; ++kx) {
     const int k = KB * 16 + kx;
     double* buf = colbuf + (k & 1) * 128;
     if (tx == kx) {
 #pragma unroll
-      for (int a = 0; a < 8; ++a) buf[ty + 16 * a] = R[a][KB];
+      for (int a = 0; a < 4; ++a) buf[ty + 32 * a] = Lr[a][KB];
     }
     __syncthreads();
     double d = buf[k];
@@ -41,141 +41,132 @@ __device__ __forceinline__ void chol_steps(double (&R)[8][8], double* colbuf, do
       d = 1.0;
     }
     const double rs = rc_rsqrt(d);
-    if (threadIdx.x == 0) { rsd[k] = rs; diag[k] = d * rs; }
-    double li[8], lj[8];
+    if (threadIdx.x == 0) rsd[k] = rs;
+    double li[4], lj[8];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) li[a] = buf[ty + 16 * a] * rs;
+    for (int a = KB >> 1; a < 4; ++a) li[a] = buf[ty + 32 * a] * rs;
 #pragma unroll
     for (int b = KB; b < 8; ++b) lj[b] = buf[tx + 16 * b] * rs;
     if (tx == kx) {
 #pragma unroll
-      for (int a = 0; a < 8; ++a) R[a][KB] = li[a];          // final L[i][k] for i > k (row k itself is fixed up from diag[])
+      for (int a = KB >> 1; a < 4; ++a) Lr[a][KB] = li[a];   // final L[i][k], i >= k (row k gets d*rs = sqrt(d))
     }
 #pragma unroll
     for (int b = KB; b < 8; ++b) {
       if (b == KB && tx <= kx) continue;                      // only columns j > k
 #pragma unroll
-      for (int a = 0; a < 8; ++a) R[a][b] = __builtin_fma(-li[a], lj[b], R[a][b]);
+      for (int a = b >> 1; a < 4; ++a) Lr[a][b] = __builtin_fma(-li[a], lj[b], Lr[a][b]);
     }
   }
 }
 
-// Forward elimination on the identity: after step k, row k of X = L^-1 is final. Rows i > k: R[i][j] -= L[i][k] X[k][j].
+// Forward elimination on the identity: at step k row k of X = L^-1 becomes final, then rows i > k: X[i][j] -= L[i][k] X[k][j].
 template <int KB>
-__device__ __forceinline__ void inv_steps(double (&R)[8][8], const double* S, double* rowbuf, const double* rsd, const int tx,
-                                          const int ty) {
+__device__ __forceinline__ void inv_steps(double (&Xr)[4][8], const double (&Lr)[4][8], double* colbuf, double* rowbuf, const double* rsd,
+                                          const int tx, const int ty) {
+  constexpr int AK = KB >> 1;                                 // register row-group holding row k
 #pragma unroll 1
   for (int kx = 0; kx < 16; ++kx) {
     const int k = KB * 16 + kx;
-    double* buf = rowbuf + (k & 1) * 128;
-    if (ty == kx) {                                           // owners of row k
+    const int kty = 16 * (KB & 1) + kx;                       // ty of the threads holding row k
+    double* cb = colbuf + (k & 1) * 128;
+    double* rb = rowbuf + (k & 1) * 128;
+    if (ty == kty) {
       const double rk = rsd[k];
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
         const int j = tx + 16 * b;
-        const double x = (j < k) ? R[KB][b] * rk : (j == k ? rk : 0.0);
-        R[KB][b] = x;
-        buf[j] = x;
+        const double x = (j < k) ? Xr[AK][b] * rk : (j == k ? rk : 0.0);
+        Xr[AK][b] = x;
+        rb[j] = x;
       }
+    }
+    if (tx == kx) {
+#pragma unroll
+      for (int a = AK; a < 4; ++a) cb[ty + 32 * a] = Lr[a][KB];
     }
     __syncthreads();
     double xj[8];
 #pragma unroll
-    for (int b = 0; b <= KB; ++b) xj[b] = buf[tx + 16 * b];   // X[k][j] is zero for j > k: column groups b > KB untouched
+    for (int b = 0; b <= KB; ++b) xj[b] = rb[tx + 16 * b];    // X[k][j] = 0 for j > k: column groups b > KB untouched
 #pragma unroll
-    for (int a = KB; a < 8; ++a) {
-      if (a == KB && ty <= kx) continue;                      // only rows i > k
-      const double lik = S[(ty + 16 * a) * DS + k];
+    for (int a = AK; a < 4; ++a) {
+      if (a == AK && ty <= kty) continue;                     // only rows i > k
+      const double lik = cb[ty + 32 * a];
 #pragma unroll
-      for (int b = 0; b <= KB; ++b) R[a][b] = __builtin_fma(-lik, xj[b], R[a][b]);
+      for (int b = 0; b <= KB; ++b) Xr[a][b] = __builtin_fma(-lik, xj[b], Xr[a][b]);
     }
   }
 }
 
-__global__ void __launch_bounds__(256) k_diag(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
-                                              double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
-  extern __shared__ double S[];            // [128][DS] block, then diag[128], rsd[128], rv[128], buf[2][128]
-  double* diag = S + 128 * DS;
-  double* rsd = diag + 128;
-  double* rv = rsd + 128;
-  double* buf = rv + 128;
+__global__ void __launch_bounds__(512, 2) k_diag(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
+                                                 double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
+  __shared__ double colbuf[2 * 128], rowbuf[2 * 128], rsd[128], rv[128];
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   double* At = A + j0 * ld + j0;
-  double R[8][8];
+  double Lr[4][8], Xr[4][8];
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const int i = ty + 16 * a, j = tx + 16 * b;
-      R[a][b] = (j <= i) ? At[(int64_t)i * ld + j] : 0.0;
+      const int i = ty + 32 * a, j = tx + 16 * b;
+      Lr[a][b] = (j <= i) ? At[(int64_t)i * ld + j] : 0.0;
+      Xr[a][b] = (i == j) ? 1.0 : 0.0;
     }
   if (t < 128) rv[t] = rhs[j0 + t];
 
-  chol_steps<0>(R, buf, rsd, diag, info, j0, tx, ty);
-  chol_steps<1>(R, buf, rsd, diag, info, j0, tx, ty);
-  chol_steps<2>(R, buf, rsd, diag, info, j0, tx, ty);
-  chol_steps<3>(R, buf, rsd, diag, info, j0, tx, ty);
-  chol_steps<4>(R, buf, rsd, diag, info, j0, tx, ty);
-  chol_steps<5>(R, buf, rsd, diag, info, j0, tx, ty);
-  chol_steps<6>(R, buf, rsd, diag, info, j0, tx, ty);
-  chol_steps<7>(R, buf, rsd, diag, info, j0, tx, ty);
+  chol_steps<0>(Lr, colbuf, rsd, info, j0, tx, ty);
+  chol_steps<1>(Lr, colbuf, rsd, info, j0, tx, ty);
+  chol_steps<2>(Lr, colbuf, rsd, info, j0, tx, ty);
+  chol_steps<3>(Lr, colbuf, rsd, info, j0, tx, ty);
+  chol_steps<4>(Lr, colbuf, rsd, info, j0, tx, ty);
+  chol_steps<5>(Lr, colbuf, rsd, info, j0, tx, ty);
+  chol_steps<6>(Lr, colbuf, rsd, info, j0, tx, ty);
+  chol_steps<7>(Lr, colbuf, rsd, info, j0, tx, ty);
   __syncthreads();
 
-  // L back to global (lower + diagonal, zeros above), a copy into LDS for the inverse sweep, log-diagonal
+  // L back to global (lower + diagonal, zeros above) and log-diagonal
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const int i = ty + 16 * a, j = tx + 16 * b;
-      const double v = (j < i) ? R[a][b] : (j == i ? diag[i] : 0.0);
-      At[(int64_t)i * ld + j] = v;
-      S[i * DS + j] = v;
-      R[a][b] = (i == j) ? 1.0 : 0.0;
+      const int i = ty + 32 * a, j = tx + 16 * b;
+      At[(int64_t)i * ld + j] = (j <= i) ? Lr[a][b] : 0.0;
     }
-  if (t < 128) logdiag[j0 + t] = log(diag[t]);
-  __syncthreads();
+  if (t < 128) logdiag[j0 + t] = -log(rsd[t]);              // log L_ii = log sqrt(d) = -log(1/sqrt(d))
 
-  inv_steps<0>(R, S, buf, rsd, tx, ty);
-  inv_steps<1>(R, S, buf, rsd, tx, ty);
-  inv_steps<2>(R, S, buf, rsd, tx, ty);
-  inv_steps<3>(R, S, buf, rsd, tx, ty);
-  inv_steps<4>(R, S, buf, rsd, tx, ty);
-  inv_steps<5>(R, S, buf, rsd, tx, ty);
-  inv_steps<6>(R, S, buf, rsd, tx, ty);
-  inv_steps<7>(R, S, buf, rsd, tx, ty);
-  __syncthreads();
+  inv_steps<0>(Xr, Lr, colbuf, rowbuf, rsd, tx, ty);
+  inv_steps<1>(Xr, Lr, colbuf, rowbuf, rsd, tx, ty);
+  inv_steps<2>(Xr, Lr, colbuf, rowbuf, rsd, tx, ty);
+  inv_steps<3>(Xr, Lr, colbuf, rowbuf, rsd, tx, ty);
+  inv_steps<4>(Xr, Lr, colbuf, rowbuf, rsd, tx, ty);
+  inv_steps<5>(Xr, Lr, colbuf, rowbuf, rsd, tx, ty);
+  inv_steps<6>(Xr, Lr, colbuf, rowbuf, rsd, tx, ty);
+  inv_steps<7>(Xr, Lr, colbuf, rowbuf, rsd, tx, ty);
 
-  // X = L^-1 out (row-major, zeros above the diagonal) and into LDS for w_j = X * rhs_j
+  // X = L^-1 out (row-major, zeros above the diagonal) and w_j = X * rhs_j (16 lanes share a row)
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int i = ty + 16 * a, j = tx + 16 * b;
-      const double v = (j <= i) ? R[a][b] : 0.0;
-      invL[i * 128 + j] = v;
-      S[i * DS + j] = v;
-    }
-  __syncthreads();
-  {
-    // 2 threads per row, each summing half of the (lower-triangular) row
-    const int i = t >> 1, h = t & 1;
+  for (int a = 0; a < 4; ++a) {
+    const int i = ty + 32 * a;
     double s = 0.0;
-    for (int j = h; j <= i; j += 2) s = __builtin_fma(S[i * DS + j], rv[j], s);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int j = tx + 16 * b;
+      const double v = (j <= i) ? Xr[a][b] : 0.0;
+      invL[i * 128 + j] = v;
+      s = __builtin_fma(v, rv[j], s);
+    }
     s += __shfl_xor(s, 1);
-    if (h == 0) rhs[j0 + i] = s;
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    if (tx == 0) rhs[j0 + i] = s;
   }
 }
 
 int rc_launch_diag(rcgp_handle_s* h, int64_t j) {
-  const size_t lds = (size_t)(128 * DS + 5 * 128) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    RC_HIP(hipFuncSetAttribute((const void*)k_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   RcProfScope ps(h, RC_K_DIAG, 128.0 * 128.0 * 128.0 / 3.0);
-  hipLaunchKernelGGL(k_diag, dim3(1), dim3(256), lds, h->stream, h->A, h->Np, h->invdiag + (j / 128) * 128 * 128, h->w, h->logdiag, h->info,
-                     j);
+  hipLaunchKernelGGL(k_diag, dim3(1), dim3(512), 0, h->stream, h->A, h->Np, h->invdiag + (j / 128) * 128 * 128, h->w, h->logdiag, h->info, j);
   RC_HIP(hipGetLastError());
   return 0;
 }
