@@ -2,6 +2,8 @@
 #include "../../include/rcgp.h"
 #include "common.h"
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define RC_API extern "C" __attribute__((visibility("default")))
@@ -29,7 +31,11 @@ static void free_all(rcgp_handle_s* h) {
   h->prof_events.clear();
   for (auto& e : h->event_pool) (void)hipEventDestroy(e);
   h->event_pool.clear();
-  if (h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
+  for (auto& e : h->la_events) (void)hipEventDestroy(e);
+  h->la_events.clear();
+  if (h->stream3) { (void)hipStreamDestroy(h->stream3); h->stream3 = nullptr; }
+  if (h->stream2) { (void)hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
+  if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
 }
 
 static std::string g_create_error;
@@ -48,6 +54,31 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   const int M = h->M;
   RC_HIP(hipSetDevice(h->device));
   RC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0;
+    RC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // hi is the numerically lowest = highest priority
+    RC_HIP(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
+  }
+  {
+    // The bulk-update stream may use every CU except the first RCGP_RESERVE_CUS, which stay free for the panel chain.
+    int reserve = 24;
+    if (const char* e = getenv("RCGP_RESERVE_CUS")) reserve = atoi(e);
+    hipDeviceProp_t prop;
+    RC_HIP(hipGetDeviceProperties(&prop, h->device));
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int cu = 0; cu < ncu; ++cu)
+      if (cu >= reserve) mask[cu / 32] |= (1u << (cu % 32));
+    hipError_t me = hipErrorInvalidValue;
+    if (reserve > 0 && reserve < ncu) me = hipExtStreamCreateWithCUMask(&h->stream3, (uint32_t)mask.size(), mask.data());
+    if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] %d CUs, reserve %d, CU-mask stream: %s\n", ncu, reserve, hipGetErrorString(me));
+    if (me != hipSuccess) {
+      (void)hipGetLastError();
+      RC_HIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    }
+  }
+  h->launch = h->stream;
+  if (const char* e = getenv("RCGP_LOOKAHEAD")) h->lookahead = (e[0] != '0');     // tuning knob: 0 = strictly sequential potrf
   RC_HIP(hipMalloc(&h->X, (size_t)Np * M * sizeof(double)));
   RC_HIP(hipMalloc(&h->Z, (size_t)Np * M * sizeof(double)));
   RC_HIP(hipMalloc(&h->sq, (size_t)Np * sizeof(double)));

@@ -27,7 +27,12 @@ struct RcProfEvent { hipEvent_t start, stop; int cls; };
 
 struct rcgp_handle_s {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // main stream: every public call is ordered on it
+  hipStream_t stream2 = nullptr;     // high-priority side stream: look-ahead panel factorisation inside rc_potrf
+  hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky (normal priority)
+  hipStream_t launch = nullptr;      // the stream kernels are currently launched on (stream or stream2)
+  std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing)
+  bool lookahead = true;
   int64_t N = 0, Np = 0;       // rows, rows padded to a multiple of RC_TILE
   int M = 0;
   // hyper-parameters (constrained space)
@@ -81,8 +86,8 @@ struct rcgp_handle_s {
 
 // RAII-less profiling bracket: records events around one kernel launch when profiling is on.
 struct RcProfScope {
-  rcgp_handle_s* h; int idx;
-  RcProfScope(rcgp_handle_s* h_, int cls, double work) : h(h_), idx(-1) {
+  rcgp_handle_s* h; int idx; hipStream_t st;
+  RcProfScope(rcgp_handle_s* h_, int cls, double work) : h(h_), idx(-1), st(h_->launch) {
     if (!h->profiling) return;
     RcProfEvent ev; ev.cls = cls;
     auto take = [&](hipEvent_t* e) {
@@ -90,12 +95,12 @@ struct RcProfScope {
       return hipEventCreate(e) == hipSuccess;
     };
     if (!take(&ev.start) || !take(&ev.stop)) return;
-    (void)hipEventRecord(ev.start, h->stream);
+    (void)hipEventRecord(ev.start, h->launch);
     h->prof_events.push_back(ev);
     idx = (int)h->prof_events.size() - 1;
     h->prof_work[cls] += work;
   }
-  ~RcProfScope() { if (idx >= 0) (void)hipEventRecord(h->prof_events[idx].stop, h->stream); }
+  ~RcProfScope() { if (idx >= 0) (void)hipEventRecord(h->prof_events[idx].stop, st); }
 };
 
 // ---- gram.hip

@@ -182,7 +182,7 @@ int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double*
   const int64_t T = n / 128;
   if (T <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, (double)n * (double)(n + 128) * (double)kk);   // 2*kk flops per lower-tile element
-  hipLaunchKernelGGL(k_syrk_lower<RC_WN>, dim3((unsigned)(T * (T + 1) / 2)), dim3(128 * RC_WN), 0, h->stream, C, ldc, P, ldp, (int)kk);
+  hipLaunchKernelGGL(k_syrk_lower<RC_WN>, dim3((unsigned)(T * (T + 1) / 2)), dim3(128 * RC_WN), 0, h->launch, C, ldc, P, ldp, (int)kk);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -207,7 +207,7 @@ int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0) {
   if (m <= 0 || n <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)m * (double)n * (double)kk);
-  hipLaunchKernelGGL(k_gemm_nt_sub<RC_WN>, dim3((unsigned)(n / 128), (unsigned)(m / 128)), dim3(128 * RC_WN), 0, h->stream, C, ldc, A, lda,
+  hipLaunchKernelGGL(k_gemm_nt_sub<RC_WN>, dim3((unsigned)(n / 128), (unsigned)(m / 128)), dim3(128 * RC_WN), 0, h->launch, C, ldc, A, lda,
                      B, ldb, (int)kk, row0, col0);
   RC_HIP(hipGetLastError());
   return 0;
@@ -261,7 +261,7 @@ __global__ void RC_BOUNDS(WN) k_trsm_panel(double* __restrict__ P, int64_t ldp, 
 int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double* invL, int64_t m, double* rhs, const double* wj) {
   if (m <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, (double)m * 128.0 * 128.0);     // triangular: m*128*128 flops algorithmic
-  hipLaunchKernelGGL(k_trsm_panel<RC_WN>, dim3((unsigned)(m / 128)), dim3(128 * RC_WN), 0, h->stream, P, ldp, invL, rhs, wj);
+  hipLaunchKernelGGL(k_trsm_panel<RC_WN>, dim3((unsigned)(m / 128)), dim3(128 * RC_WN), 0, h->launch, P, ldp, invL, rhs, wj);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -274,7 +274,7 @@ template <int WN>
 __global__ void RC_BOUNDS(WN) k_trtri_T(const double* __restrict__ Lm, const double* __restrict__ W, double* __restrict__ S, int64_t ld,
                                         int64_t Np, int64_t s) {
   __shared__ double lds[GEMM_LDS];
-  const int tj = blockIdx.x, ti = blockIdx.y;
+  const int ti = blockIdx.x, tj = blockIdx.y;                 // tj slow: the longest k-ranges (small tj) are dispatched first
   const int64_t colA = 2 * s * (int64_t)blockIdx.z, rowC = colA + s;
   if (rowC + (int64_t)ti * 128 >= Np) return;
   v4d acc[4][Geo<WN>::NI];
@@ -288,7 +288,7 @@ __global__ void RC_BOUNDS(WN) k_trtri_T(const double* __restrict__ Lm, const dou
 template <int WN>
 __global__ void RC_BOUNDS(WN) k_trtri_X(double* __restrict__ W, const double* __restrict__ S, int64_t ld, int64_t Np, int64_t s) {
   __shared__ double lds[GEMM_LDS];
-  const int tj = blockIdx.x, ti = blockIdx.y;
+  const int tj = blockIdx.x, ti = (int)gridDim.y - 1 - (int)blockIdx.y;   // ti slow and reversed: longest k-ranges first
   const int64_t colA = 2 * s * (int64_t)blockIdx.z, rowC = colA + s;
   if (rowC + (int64_t)ti * 128 >= Np) return;
   v4d acc[4][Geo<WN>::NI];
@@ -310,13 +310,13 @@ int rc_launch_trtri_level(rcgp_handle_s* h, int64_t s) {
   if (npairs == 0) return 0;
   {
     RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)s * (double)s * (double)s);
-    hipLaunchKernelGGL(k_trtri_T<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->stream, h->A, h->Linv,
+    hipLaunchKernelGGL(k_trtri_T<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->launch, h->A, h->Linv,
                        h->S, Np, Np, s);
     RC_HIP(hipGetLastError());
   }
   {
     RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)s * (double)s * (double)s);
-    hipLaunchKernelGGL(k_trtri_X<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->stream, h->Linv, h->S,
+    hipLaunchKernelGGL(k_trtri_X<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->S,
                        Np, Np, s);
     RC_HIP(hipGetLastError());
   }
@@ -426,10 +426,10 @@ int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
   const double np = (double)h->Np;
   RcProfScope ps(h, RC_K_GEMM, np * np * np / 3.0);
   if (h->M <= 32)
-    hipLaunchKernelGGL((k_grad<33, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->stream, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
+    hipLaunchKernelGGL((k_grad<33, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
                        h->sq, h->alpha, h->var, h->partial);
   else
-    hipLaunchKernelGGL((k_grad<65, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->stream, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
+    hipLaunchKernelGGL((k_grad<65, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
                        h->sq, h->alpha, h->var, h->partial);
   RC_HIP(hipGetLastError());
   *nrows = (int)nb;
@@ -481,13 +481,13 @@ int rc_launch_predict_var(rcgp_handle_s* h, int64_t np) {
   if (rc) return rc;
   {
     RcProfScope ps(h, RC_K_GEMM, (double)h->Np * (double)h->Np * (double)np);
-    hipLaunchKernelGGL(k_predict_var<RC_WN>, dim3((unsigned)(np / 128), (unsigned)T), dim3(128 * RC_WN), 0, h->stream, h->Linv, h->Np, h->KsT,
+    hipLaunchKernelGGL(k_predict_var<RC_WN>, dim3((unsigned)(np / 128), (unsigned)T), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->KsT,
                        h->Np, np, h->partial);
     RC_HIP(hipGetLastError());
   }
   {
     RcProfScope ps(h, RC_K_MISC, 0.0);
-    hipLaunchKernelGGL(k_colreduce, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream, h->partial, T, np, h->pvar);
+    hipLaunchKernelGGL(k_colreduce, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->launch, h->partial, T, np, h->pvar);
     RC_HIP(hipGetLastError());
   }
   return 0;

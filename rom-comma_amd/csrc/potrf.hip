@@ -23,85 +23,125 @@ __device__ __forceinline__ double rc_rsqrt(double d) {
 // communication is one 128-entry column (and, for the inverse, one row) through LDS and ONE barrier.
 // KB = k >> 4 is a template parameter so that every register index is static; blocks strictly above the diagonal
 // (b >= 2a + 2) are never touched.
+// Two pivots (columns k, k+1) per barrier: the owners publish both raw columns, then every thread factors the 2x2 pivot
+// block redundantly and applies the rank-2 update to its own elements -- half the synchronisations of a column-at-a-time sweep.
 template <int KB>
 __device__ __forceinline__ void chol_steps(double (&Lr)[4][8], double* colbuf, double* rsd, int* info, int64_t j0, const int tx,
                                            const int ty) {
+  constexpr int A0 = KB >> 1;                                 // first register row-group that can lie on/below the diagonal
 #pragma unroll 1
-  for (int kx = 0; kx < 16; ++kx) {
-    const int k = KB * 16 + kx;
-    double* buf = colbuf + (k & 1) * 128;
+  for (int q = 0; q < 8; ++q) {
+    const int kx = 2 * q, k = KB * 16 + kx;
+    double* c0 = colbuf + (q & 1) * 256;
+    double* c1 = c0 + 128;
     if (tx == kx) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) buf[ty + 32 * a] = Lr[a][KB];
+      for (int a = A0; a < 4; ++a) c0[ty + 32 * a] = Lr[a][KB];
+    } else if (tx == kx + 1) {
+#pragma unroll
+      for (int a = A0; a < 4; ++a) c1[ty + 32 * a] = Lr[a][KB];
     }
     __syncthreads();
-    double d = buf[k];
-    if (!(d > 0.0)) {                       // not positive definite (or NaN): flag the leading minor, keep going finite
+    double d0 = c0[k];
+    if (!(d0 > 0.0)) {                      // not positive definite (or NaN): flag the leading minor, keep going finite
       if (threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + k + 1));
-      d = 1.0;
+      d0 = 1.0;
     }
-    const double rs = rc_rsqrt(d);
-    if (threadIdx.x == 0) rsd[k] = rs;
-    double li[4], lj[8];
+    const double rs0 = rc_rsqrt(d0);
+    const double l10 = c0[k + 1] * rs0;                       // L[k+1][k]
+    double d1 = __builtin_fma(-l10, l10, c1[k + 1]);
+    if (!(d1 > 0.0)) {
+      if (threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + k + 2));
+      d1 = 1.0;
+    }
+    const double rs1 = rc_rsqrt(d1);
+    if (threadIdx.x == 0) { rsd[k] = rs0; rsd[k + 1] = rs1; }
+    double li0[4], li1[4], lj0[8], lj1[8];
 #pragma unroll
-    for (int a = KB >> 1; a < 4; ++a) li[a] = buf[ty + 32 * a] * rs;
-#pragma unroll
-    for (int b = KB; b < 8; ++b) lj[b] = buf[tx + 16 * b] * rs;
-    if (tx == kx) {
-#pragma unroll
-      for (int a = KB >> 1; a < 4; ++a) Lr[a][KB] = li[a];   // final L[i][k], i >= k (row k gets d*rs = sqrt(d))
+    for (int a = A0; a < 4; ++a) {
+      li0[a] = c0[ty + 32 * a] * rs0;
+      li1[a] = __builtin_fma(-li0[a], l10, c1[ty + 32 * a]) * rs1;
     }
 #pragma unroll
     for (int b = KB; b < 8; ++b) {
-      if (b == KB && tx <= kx) continue;                      // only columns j > k
+      lj0[b] = c0[tx + 16 * b] * rs0;
+      lj1[b] = __builtin_fma(-lj0[b], l10, c1[tx + 16 * b]) * rs1;
+    }
+    if (tx == kx) {
 #pragma unroll
-      for (int a = b >> 1; a < 4; ++a) Lr[a][b] = __builtin_fma(-li[a], lj[b], Lr[a][b]);
+      for (int a = A0; a < 4; ++a) Lr[a][KB] = li0[a];        // final L[i][k]   (row k itself: d0*rs0 = sqrt(d0))
+    } else if (tx == kx + 1) {
+#pragma unroll
+      for (int a = A0; a < 4; ++a) Lr[a][KB] = li1[a];        // final L[i][k+1] (row k+1: d1*rs1 = sqrt(d1))
+    }
+#pragma unroll
+    for (int b = KB; b < 8; ++b) {
+      if (b == KB && tx <= kx + 1) continue;                  // only columns j > k+1
+#pragma unroll
+      for (int a = b >> 1; a < 4; ++a) Lr[a][b] = __builtin_fma(-li1[a], lj1[b], __builtin_fma(-li0[a], lj0[b], Lr[a][b]));
     }
   }
 }
 
-// Forward elimination on the identity: at step k row k of X = L^-1 becomes final, then rows i > k: X[i][j] -= L[i][k] X[k][j].
+// Forward elimination on the identity, two rows (k, k+1) per barrier: rows k and k+1 of X = L^-1 become final, then
+// rows i > k+1: X[i][j] -= L[i][k] X[k][j] + L[i][k+1] X[k+1][j].
 template <int KB>
 __device__ __forceinline__ void inv_steps(double (&Xr)[4][8], const double (&Lr)[4][8], double* colbuf, double* rowbuf, const double* rsd,
                                           const int tx, const int ty) {
-  constexpr int AK = KB >> 1;                                 // register row-group holding row k
+  constexpr int AK = KB >> 1;                                 // register row-group holding rows k, k+1
 #pragma unroll 1
-  for (int kx = 0; kx < 16; ++kx) {
-    const int k = KB * 16 + kx;
-    const int kty = 16 * (KB & 1) + kx;                       // ty of the threads holding row k
-    double* cb = colbuf + (k & 1) * 128;
-    double* rb = rowbuf + (k & 1) * 128;
+  for (int q = 0; q < 8; ++q) {
+    const int kx = 2 * q, k = KB * 16 + kx;
+    const int kty = 16 * (KB & 1) + kx;                       // ty of the threads holding row k (row k+1: kty + 1)
+    double* c0 = colbuf + (q & 1) * 256;
+    double* c1 = c0 + 128;
+    double* r0 = rowbuf + (q & 1) * 256;
+    double* r1 = r0 + 128;
     if (ty == kty) {
-      const double rk = rsd[k];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int j = tx + 16 * b;
-        const double x = (j < k) ? Xr[AK][b] * rk : (j == k ? rk : 0.0);
-        Xr[AK][b] = x;
-        rb[j] = x;
-      }
+      for (int b = 0; b <= KB; ++b) r0[tx + 16 * b] = Xr[AK][b];
+    } else if (ty == kty + 1) {
+#pragma unroll
+      for (int b = 0; b <= KB; ++b) r1[tx + 16 * b] = Xr[AK][b];
     }
     if (tx == kx) {
 #pragma unroll
-      for (int a = AK; a < 4; ++a) cb[ty + 32 * a] = Lr[a][KB];
+      for (int a = AK; a < 4; ++a) c0[ty + 32 * a] = Lr[a][KB];
+    } else if (tx == kx + 1) {
+#pragma unroll
+      for (int a = AK; a < 4; ++a) c1[ty + 32 * a] = Lr[a][KB];
     }
     __syncthreads();
-    double xj[8];
+    const double rk0 = rsd[k], rk1 = rsd[k + 1];
+    const double l10 = c0[k + 1];                              // L[k+1][k]
+    double x0[8], x1[8];
 #pragma unroll
-    for (int b = 0; b <= KB; ++b) xj[b] = rb[tx + 16 * b];    // X[k][j] = 0 for j > k: column groups b > KB untouched
+    for (int b = 0; b <= KB; ++b) {
+      const int j = tx + 16 * b;
+      x0[b] = (j < k) ? r0[j] * rk0 : (j == k ? rk0 : 0.0);
+      x1[b] = (j <= k) ? __builtin_fma(-l10, x0[b], r1[j]) * rk1 : (j == k + 1 ? rk1 : 0.0);
+    }
+    if (ty == kty) {
+#pragma unroll
+      for (int b = 0; b <= KB; ++b) Xr[AK][b] = x0[b];
+    } else if (ty == kty + 1) {
+#pragma unroll
+      for (int b = 0; b <= KB; ++b) Xr[AK][b] = x1[b];
+    }
 #pragma unroll
     for (int a = AK; a < 4; ++a) {
-      if (a == AK && ty <= kty) continue;                     // only rows i > k
-      const double lik = cb[ty + 32 * a];
+      if (a == AK && ty <= kty + 1) continue;                 // only rows i > k+1
+      const double l0 = c0[ty + 32 * a], l1 = c1[ty + 32 * a];
 #pragma unroll
-      for (int b = 0; b <= KB; ++b) Xr[a][b] = __builtin_fma(-lik, xj[b], Xr[a][b]);
+      for (int b = 0; b <= KB; ++b) Xr[a][b] = __builtin_fma(-l1, x1[b], __builtin_fma(-l0, x0[b], Xr[a][b]));
     }
   }
 }
 
 __global__ void __launch_bounds__(512, 2) k_diag(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
                                                  double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
-  __shared__ double colbuf[2 * 128], rowbuf[2 * 128], rsd[128], rv[128];
+  __shared__ double colbuf[4 * 128], rowbuf[4 * 128], rsd[128], rv[128];
+  __builtin_amdgcn_s_setprio(3);             // latency-critical: win issue arbitration against co-resident GEMM waves
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   double* At = A + j0 * ld + j0;
   double Lr[4][8], Xr[4][8];
@@ -166,33 +206,82 @@ __global__ void __launch_bounds__(512, 2) k_diag(double* __restrict__ A, int64_t
 
 int rc_launch_diag(rcgp_handle_s* h, int64_t j) {
   RcProfScope ps(h, RC_K_DIAG, 128.0 * 128.0 * 128.0 / 3.0);
-  hipLaunchKernelGGL(k_diag, dim3(1), dim3(512), 0, h->stream, h->A, h->Np, h->invdiag + (j / 128) * 128 * 128, h->w, h->logdiag, h->info, j);
+  hipLaunchKernelGGL(k_diag, dim3(1), dim3(512), 0, h->launch, h->A, h->Np, h->invdiag + (j / 128) * 128 * 128, h->w, h->logdiag, h->info, j);
   RC_HIP(hipGetLastError());
   return 0;
 }
 
-int rc_potrf(rcgp_handle_s* h) {
+// Factor the outer panel of columns [J, Jend): for every 128-column block the diagonal kernel, the panel solve for all rows
+// below, and the update of the panel's remaining columns. Launched on h->launch.
+static int panel_factor(rcgp_handle_s* h, int64_t J, int64_t Jend) {
   const int64_t Np = h->Np;
   int rc;
+  for (int64_t j = J; j < Jend; j += 128) {
+    if ((rc = rc_launch_diag(h, j))) return rc;
+    const int64_t below = Np - (j + 128);
+    if (below <= 0) continue;
+    double* P = h->A + (j + 128) * Np + j;                       // rows below the diagonal block, 128 columns
+    if ((rc = rc_launch_trsm_panel(h, P, Np, h->invdiag + (j / 128) * 128 * 128, below, h->w + j + 128, h->w + j))) return rc;
+    const int64_t rest = Jend - (j + 128);                       // remaining columns inside the outer panel
+    if (rest > 0) {
+      double* C = h->A + (j + 128) * Np + (j + 128);
+      if ((rc = rc_launch_gemm_nt_sub(h, C, Np, P, Np, P, Np, below, rest, 128, j + 128, j + 128))) return rc;
+    }
+  }
+  return 0;
+}
+
+// Right-looking blocked Cholesky with one-panel look-ahead: as soon as the trailing update has finished the NEXT panel's
+// columns, that panel is factored on the high-priority side stream while the main stream updates the rest of the trailing
+// matrix. The panel chain (latency-bound diagonal blocks, K=128 GEMMs) leaves the critical path while the bulk update is
+// longer than it.
+int rc_potrf(rcgp_handle_s* h) {
+  const int64_t Np = h->Np, NB = RC_NB_OUTER;
+  int rc;
+  h->launch = h->stream;
   RC_HIP(hipMemcpyAsync(h->w, h->y, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   RC_HIP(hipMemsetAsync(h->info, 0, sizeof(int), h->stream));
-  for (int64_t J = 0; J < Np; J += RC_NB_OUTER) {
-    const int64_t Jend = (J + RC_NB_OUTER < Np) ? J + RC_NB_OUTER : Np;
-    for (int64_t j = J; j < Jend; j += 128) {
-      if ((rc = rc_launch_diag(h, j))) return rc;
-      const int64_t below = Np - (j + 128);
-      if (below <= 0) continue;
-      double* P = h->A + (j + 128) * Np + j;                       // rows below the diagonal block, 128 columns
-      if ((rc = rc_launch_trsm_panel(h, P, Np, h->invdiag + (j / 128) * 128 * 128, below, h->w + j + 128, h->w + j))) return rc;
-      const int64_t rest = Jend - (j + 128);                       // remaining columns inside the outer panel
-      if (rest > 0) {
-        double* C = h->A + (j + 128) * Np + (j + 128);
-        if ((rc = rc_launch_gemm_nt_sub(h, C, Np, P, Np, P, Np, below, rest, 128, j + 128, j + 128))) return rc;
+  const int64_t npanels = (Np + NB - 1) / NB;
+  const bool la = h->lookahead && npanels > 2;
+  while (la && (int64_t)h->la_events.size() < 3 * npanels + 1) {
+    hipEvent_t e;
+    RC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->la_events.push_back(e);
+  }
+  if ((rc = panel_factor(h, 0, NB < Np ? NB : Np))) return rc;
+  int64_t step = 0;
+  for (int64_t J = 0; J + NB < Np; J += NB, ++step) {
+    const int64_t Jend = J + NB;
+    const int64_t Jend2 = (Jend + NB < Np) ? Jend + NB : Np;
+    const double* P = h->A + Jend * Np + J;                      // panel J below its own rows: (Np - Jend) x NB
+    // (main) the next panel's columns first
+    if ((rc = rc_launch_gemm_nt_sub(h, h->A + Jend * Np + Jend, Np, P, Np, P, Np, Np - Jend, Jend2 - Jend, NB, Jend, Jend))) return rc;
+    if (la) {
+      hipEvent_t ev_next = h->la_events[3 * step], ev_panel = h->la_events[3 * step + 1], ev_rest = h->la_events[3 * step + 2];
+      RC_HIP(hipEventRecord(ev_next, h->stream));
+      // (side, high priority) factor panel J+1
+      RC_HIP(hipStreamWaitEvent(h->stream2, ev_next, 0));
+      h->launch = h->stream2;
+      rc = panel_factor(h, Jend, Jend2);
+      h->launch = h->stream;
+      if (rc) return rc;
+      RC_HIP(hipEventRecord(ev_panel, h->stream2));
+      // (bulk stream) the rest of the trailing matrix, concurrently with the panel
+      RC_HIP(hipStreamWaitEvent(h->stream3, ev_next, 0));
+      if (Np - Jend2 > 0) {
+        h->launch = h->stream3;
+        rc = rc_launch_syrk_lower(h, h->A + Jend2 * Np + Jend2, Np, h->A + Jend2 * Np + J, Np, Np - Jend2, NB);
+        h->launch = h->stream;
+        if (rc) return rc;
       }
-    }
-    const int64_t n = Np - Jend;
-    if (n > 0) {
-      if ((rc = rc_launch_syrk_lower(h, h->A + Jend * Np + Jend, Np, h->A + Jend * Np + J, Np, n, Jend - J))) return rc;
+      RC_HIP(hipEventRecord(ev_rest, h->stream3));
+      RC_HIP(hipStreamWaitEvent(h->stream, ev_panel, 0));
+      RC_HIP(hipStreamWaitEvent(h->stream, ev_rest, 0));
+    } else {
+      if (Np - Jend2 > 0) {
+        if ((rc = rc_launch_syrk_lower(h, h->A + Jend2 * Np + Jend2, Np, h->A + Jend2 * Np + J, Np, Np - Jend2, NB))) return rc;
+      }
+      if ((rc = panel_factor(h, Jend, Jend2))) return rc;
     }
   }
   h->factored = true;
