@@ -2,7 +2,7 @@
 // This is GPflow's square_distance expansion (no clamp), the arithmetic behind gf.kernels.RBF.K at the reference call
 // sites gpr/kernels.py:176 and gpr/models.py:435-437 (the +noise on the diagonal is fused here).
 //
-// One workgroup = one 128x128 tile, 256 threads, 8x8 outputs per thread; the two Z panels (128 x M each) are staged in LDS
+// One workgroup = one 128x128 tile, 512 threads, 4x8 outputs per thread; the two Z panels (128 x M each) are staged in LDS
 // m-major so that a row read is a broadcast and a column read is a contiguous double2; stores are 16 B per lane, 256 B
 // contiguous per 16 lanes. Only tiles on or below the diagonal are written (the Cholesky reads the lower triangle).
 #include "common.h"
@@ -25,7 +25,7 @@ __global__ void k_scale(const double* __restrict__ X, const double* __restrict__
 
 int rc_launch_scale_rows(rcgp_handle_s* h, const double* X, double* Z, double* sq, int64_t rows) {
   RcProfScope ps(h, RC_K_MISC, 0.0);
-  hipLaunchKernelGGL(k_scale, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, X, h->ell_d, Z, sq, rows, h->M);
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->launch, X, h->ell_d, Z, sq, rows, h->M);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -42,10 +42,12 @@ __device__ __forceinline__ void tri_decode_g(int64_t id, int& ti, int& tj) {
 
 // CROSS = false: square Gram, lower tiles, + noise on the diagonal, identity on the padding.
 // CROSS = true : rectangular cross-Gram out[row = test point][col = training point], zero on the padding.
+// 512 threads per 128x128 tile, 4x8 outputs per thread (rows ty + 32a, column pairs 2tx + 32b): <= 128 registers, so four
+// waves per SIMD are resident and the store phase of one wave overlaps the exp phase of the others.
 template <bool CROSS>
-__global__ void __launch_bounds__(256) k_gram(double* __restrict__ out, int64_t ld, const double* __restrict__ Zr,
-                                              const double* __restrict__ sqr, int64_t nr_valid, const double* __restrict__ Zc,
-                                              const double* __restrict__ sqc, int64_t nc_valid, int M, double var, double noise) {
+__global__ void __launch_bounds__(512, 4) k_gram(double* __restrict__ out, int64_t ld, const double* __restrict__ Zr,
+                                                 const double* __restrict__ sqr, int64_t nr_valid, const double* __restrict__ Zc,
+                                                 const double* __restrict__ sqc, int64_t nc_valid, int M, double var, double noise) {
   extern __shared__ double sm[];
   double* zi = sm;                 // [M][ZST]
   double* zj = sm + M * ZST;       // [M][ZST]
@@ -59,29 +61,29 @@ __global__ void __launch_bounds__(256) k_gram(double* __restrict__ out, int64_t 
     tri_decode_g(blockIdx.x, ti, tj);
   }
   const int t = threadIdx.x;
-  for (int e = t; e < 128 * M; e += 256) {
+  for (int e = t; e < 128 * M; e += 512) {
     const int rr = e / M, m = e - rr * M;
     zi[m * ZST + rr] = Zr[((int64_t)ti * 128 + rr) * M + m];
     zj[m * ZST + rr] = Zc[((int64_t)tj * 128 + rr) * M + m];
   }
   if (t < 128) si[t] = sqr[(int64_t)ti * 128 + t];
-  else sj[t - 128] = sqc[(int64_t)tj * 128 + t - 128];
+  else if (t < 256) sj[t - 128] = sqc[(int64_t)tj * 128 + t - 128];
   __syncthreads();
   const int tx = t & 15, ty = t >> 4;
-  double acc[8][8];
+  double acc[4][8];
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[a][c] = 0.0;
   for (int m = 0; m < M; ++m) {
-    double ra[8];
+    double ra[4];
     double2 cb[4];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) ra[a] = zi[m * ZST + ty + 16 * a];
+    for (int a = 0; a < 4; ++a) ra[a] = zi[m * ZST + ty + 32 * a];
 #pragma unroll
     for (int b = 0; b < 4; ++b) cb[b] = *reinterpret_cast<const double2*>(zj + m * ZST + 2 * tx + 32 * b);
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         acc[a][2 * b] = fma(ra[a], cb[b].x, acc[a][2 * b]);
@@ -89,8 +91,8 @@ __global__ void __launch_bounds__(256) k_gram(double* __restrict__ out, int64_t 
       }
   }
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    const int row = ty + 16 * a;
+  for (int a = 0; a < 4; ++a) {
+    const int row = ty + 32 * a;
     const int64_t i = (int64_t)ti * 128 + row;
     const double sia = si[row];
 #pragma unroll
@@ -109,7 +111,9 @@ __global__ void __launch_bounds__(256) k_gram(double* __restrict__ out, int64_t 
         if (i >= nr_valid || j >= nc_valid) v.x = (i == j) ? 1.0 : 0.0;
         if (i >= nr_valid || j + 1 >= nc_valid) v.y = (i == j + 1) ? 1.0 : 0.0;
       }
-      *reinterpret_cast<double2*>(out + i * ld + j) = v;
+      double* dst = out + i * ld + j;
+      __builtin_nontemporal_store(v.x, dst);           // written once, read next by another kernel: keep it out of the way in L2
+      __builtin_nontemporal_store(v.y, dst + 1);
     }
   }
 }
@@ -122,7 +126,7 @@ int rc_launch_gram(rcgp_handle_s* h) {
   RC_HIP(hipFuncSetAttribute((const void*)k_gram<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const double N = (double)h->N;
   RcProfScope ps(h, RC_K_GRAM, 8.0 * (N * (N + 1.0) / 2.0 + N * (double)h->M));   // algorithmic bytes
-  hipLaunchKernelGGL(k_gram<false>, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), lds, h->stream, h->A, h->Np, h->Z, h->sq, h->N, h->Z,
+  hipLaunchKernelGGL(k_gram<false>, dim3((unsigned)(T * (T + 1) / 2)), dim3(512), lds, h->launch, h->A, h->Np, h->Z, h->sq, h->N, h->Z,
                      h->sq, h->N, h->M, h->var, h->noise);
   RC_HIP(hipGetLastError());
   return 0;
@@ -132,7 +136,7 @@ int rc_launch_cross_gram(rcgp_handle_s* h, int64_t n, int64_t np) {
   const size_t lds = gram_lds_bytes(h->M);
   RC_HIP(hipFuncSetAttribute((const void*)k_gram<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   RcProfScope ps(h, RC_K_MISC, 0.0);
-  hipLaunchKernelGGL(k_gram<true>, dim3((unsigned)(h->Np / 128), (unsigned)(np / 128)), dim3(256), lds, h->stream, h->KsT, h->Np, h->Zs,
+  hipLaunchKernelGGL(k_gram<true>, dim3((unsigned)(h->Np / 128), (unsigned)(np / 128)), dim3(512), lds, h->launch, h->KsT, h->Np, h->Zs,
                      h->sqs, n, h->Z, h->sq, h->N, h->M, h->var, 0.0);
   RC_HIP(hipGetLastError());
   return 0;
