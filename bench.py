@@ -39,6 +39,19 @@ def sobol_indices(V, M):
     return np.concatenate([V[:M] / full, V[M:2 * M] / full, 1.0 - V[2 * M:3 * M] / full])
 
 
+def pmc_traffic(N, M):
+    """HBM bytes per launch of the GEMM family from the committed rocprofv3 --pmc passes (profiles/r01_pmc_c2.json, produced
+    by tools/pmc_summary.py with the gfx950 FETCH_SIZE correction). Counters cannot be read inside this process, so the number
+    is the profiled one for the same workload; None for any other size."""
+    path = ROOT / 'profiles' / 'r01_pmc_c2.json'
+    if (N, M) != (16384, 10) or not path.exists():
+        return None
+    try:
+        return float(json.load(open(path))['_gemm_family']['hbm_bytes_per_launch'])
+    except Exception:
+        return None
+
+
 def cpu_baseline(N, M, nfev):
     """The oracle timed on this box's host cores on a bounded sample, scaled to the workload (N^3 for an LML+gradient
     evaluation, N^2 for the Sobol quadratic forms)."""
@@ -135,7 +148,7 @@ def main():
                        'N': N, 'M': M, 'lbfgs_evaluations_last_step': nfev, 'parallelism': f'fold-per-gpu x{world}',
                        'log_marginal': last['fit']['log_marginal']},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic(N, M),
                          'kernel': 'fp64 MFMA GEMM family (Cholesky trailing update/trsm, L^-1, fused K^-1+gradient)',
                          'launches': int(n_gemm), 'avg_launch_ms': ms_gemm / max(n_gemm, 1),
                          'algorithmic_flops_per_launch': flops / max(n_gemm, 1)},
