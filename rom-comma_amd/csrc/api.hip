@@ -78,6 +78,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     }
   }
   h->launch = h->stream;
+  if (const char* e = getenv("RCGP_DIAG")) h->diag_variant = atoi(e);
   if (const char* e = getenv("RCGP_LOOKAHEAD")) h->lookahead = (e[0] != '0');     // tuning knob: 0 = strictly sequential potrf
   RC_HIP(hipMalloc(&h->X, (size_t)Np * M * sizeof(double)));
   RC_HIP(hipMalloc(&h->Z, (size_t)Np * M * sizeof(double)));
