@@ -7,7 +7,8 @@ One step = one pass of the hot path over one synthetic fold resident in HBM: L-B
 reference's default start (ell 5.0, variance 2.0, noise 0.02; gpr/kernels.py:49-50, gpr/models.py:52) with the reference's
 optimiser options (maxiter 5000, gtol 1e-16; gpr/models.py:327-330) to convergence, then the closed-form first-order /
 closed / total Sobol indices (3M+1 quadratic forms), then the gather of every rank's indices (RCCL when N > 1).
-Weak scaling: rank r owns fold k = r (its own N x M design); value = ranks * N * steps / max-over-ranks wall time.
+Weak scaling: rank r owns fold r of an 8-fold split of one seeded dataset (every fold trains on N rows); value = ranks * N *
+steps / max-over-ranks wall time.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -85,24 +86,26 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--n', type=int, default=16384, help='training rows per fold (BASELINE configs[2]: 16384)')
-    ap.add_argument('--m', type=int, default=10, help='input dimensions (BASELINE configs[2]: 10)')
+    ap.add_argument('--rows', dest='n', type=int, default=16384, help='training rows per fold (BASELINE configs[2]: 16384)')
+    ap.add_argument('--dims', dest='m', type=int, default=10, help='input dimensions (BASELINE configs[2]: 10)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='initialise the process group even for one rank (exercises RCCL on a 1-GPU box)')
     args = ap.parse_args()
 
     from romcomma_amd import _lib, dist
     from romcomma_amd.gpr.optimize import fit_lbfgsb
-    from romcomma_amd.user.sample import synthetic_fold
+    from romcomma_amd.user.sample import synthetic_cv_fold
 
     rank, world, local_rank = dist.env_rank_world()
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.init_process_group()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     if _lib.device_count() <= 0:
         raise SystemExit('bench.py needs a GPU: librcgp has no CPU fallback')
 
     N, M = args.n, args.m
-    X, y = synthetic_fold(N, M, k=rank)
+    K_folds = max(8, world)                          # fold r of a K-fold split of one seeded dataset: every fold trains on N rows
+    X, y = synthetic_cv_fold(N, M, k=rank, K=K_folds)
     gp = _lib.RcGP(X, y, device=local_rank)         # inputs resident in HBM from here on
     slices = all_slices(M)
     last = {}
@@ -143,8 +146,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'C2: ARD-RBF GP fit (L-BFGS-B to convergence, reference defaults) + closed-form Sobol first/closed/'
-                                   f'total indices, N={N}, M={M}, L=1, one fold per GPU',
+            'config': {'workload': f'{"C2" if (N, M) == (16384, 10) else "custom"}: ARD-RBF GP fit (L-BFGS-B to convergence, reference defaults) + closed-form Sobol first/closed/'
+                                   f'total indices, N={N}, M={M}, L=1, fold r of an {K_folds}-fold split per GPU',
                        'N': N, 'M': M, 'lbfgs_evaluations_last_step': nfev, 'parallelism': f'fold-per-gpu x{world}',
                        'log_marginal': last['fit']['log_marginal']},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -164,7 +167,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(N, M, nfev)
         print(json.dumps(out), flush=True)
     gp.close()
-    if world > 1:
+    if dist.is_distributed():
         import torch.distributed as td
         td.destroy_process_group()
 

@@ -23,8 +23,6 @@ def init_process_group(backend: str | None = None):
     import torch
     import torch.distributed as dist
     rank, world, local_rank = env_rank_world()
-    if world == 1 and 'MASTER_ADDR' not in os.environ:
-        return rank, world, local_rank
     if not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -39,8 +37,10 @@ def init_process_group(backend: str | None = None):
 
 
 def is_distributed() -> bool:
+    """True once a process group exists (a world of one still runs the real collectives: that is how the RCCL path is
+    exercised on a single-GPU box)."""
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_units(n_units: int, rank: int, world: int) -> List[int]:

@@ -25,7 +25,7 @@ from romcomma_amd.user import contexts, results
 def _my_folds(repo: Repository) -> List[int]:
     rank, world, _ = dist.env_rank_world()
     folds = list(repo.folds)
-    return [folds[i] for i in dist.shard_units(len(folds), rank, world)] if dist.is_distributed() else folds
+    return [folds[i] for i in dist.shard_units(len(folds), rank, world)] if world > 1 else folds
 
 
 def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | None, is_isotropic: bool | None,

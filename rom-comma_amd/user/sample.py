@@ -32,3 +32,19 @@ def synthetic_fold(N: int, M: int, k: int = 0, l: int = 0, noise: float = 0.04) 
 def bench_hyper(M: int) -> Tuple[np.ndarray, float, float]:
     """Fixed hyper-parameters for kernel-level benchmarks: ell_m = 0.5 + 3.5 m/(M-1), variance 1, noise 1.6e-3."""
     return 0.5 + 3.5 * np.arange(M) / max(M - 1, 1), 1.0, 1.6e-3
+
+
+def synthetic_cv_fold(N: int, M: int, k: int, K: int = 8, l: int = 0, noise: float = 0.04) -> Tuple[np.ndarray, np.ndarray]:
+    """Training rows of fold ``k`` of a K-fold split of ONE seeded synthetic dataset, sized so that every fold trains on
+    exactly N rows: the dataset has N + h rows, h = ceil(N/(K-1)), and fold k leaves out the k-th block of h rows (the last
+    block is shifted back to fit) -- what ``Repository.into_K_folds(-K)`` produces (data/storage.py:162-204, blocks instead of the reference's
+    unseeded shuffle). Folds overlap in (K-2)/(K-1) of their rows, as real cross-validation folds do, so their fits cost
+    about the same; normalisation uses the whole dataset, like the repository-level normalization.csv."""
+    if not (0 <= k < K) or K < 2:
+        raise ValueError(f'need 0 <= k < K and K >= 2, got k={k}, K={K}')
+    held = -(-N // (K - 1))
+    X, y = synthetic_fold(N + held, M, k=0, l=l, noise=noise)
+    start = min(k * held, N)
+    keep = np.ones(N + held, dtype=bool)
+    keep[start:start + held] = False
+    return np.ascontiguousarray(X[keep]), np.ascontiguousarray(y[keep])

@@ -157,6 +157,18 @@ def test_synthetic_generator_matches_oracle_copy():
     assert abs(a[1].mean()) < 1e-12 and a[1].std() == pytest.approx(1.0)
 
 
+def test_synthetic_cv_folds():
+    from romcomma_amd.user.sample import synthetic_cv_fold
+    folds = [synthetic_cv_fold(700, 3, k, K=8) for k in range(8)]
+    assert all(X.shape == (700, 3) and y.shape == (700,) for X, y in folds)
+    full_X, _ = synthetic_fold(800, 3)                                   # 700 + ceil(700/7) rows in the underlying dataset
+    assert np.array_equal(folds[0][0], full_X[100:])                     # fold 0 leaves out the first block
+    assert np.array_equal(folds[3][0], np.concatenate([full_X[:300], full_X[400:]]))
+    assert np.array_equal(folds[7][0], full_X[:700])
+    with pytest.raises(ValueError):
+        synthetic_cv_fold(700, 3, 8, K=8)
+
+
 def test_hipgp_refuses_covariant_and_missing_gpu(tmp_path):
     from romcomma_amd import _lib
     from romcomma_amd.gpr.models import MOGP
