@@ -190,3 +190,33 @@ def test_literal_golden_fixture():
     for s, sl in enumerate(z['slices']):
         np.testing.assert_allclose(clo.marginalize(sl)['V'], z['V'][..., s], rtol=1e-8, atol=1e-10 * np.max(np.abs(z['V0'])))
     np.testing.assert_allclose(clo.S, z['S'], rtol=1e-9)
+
+
+@pytest.mark.parametrize('L', [1, 2])
+@pytest.mark.parametrize('is_T_partial', [True, False])
+def test_sobol_error_reduced_form_matches_literal_transliteration(L, is_T_partial):
+    """Standard errors T, W (gsa/calibrators.py:146-402): the O(N^2) reduced form used by the GPU path against the op-by-op
+    transliteration of the reference's rank-equation tensor code, incl. cross-output entries and the MIXED (non-partial) path."""
+    from oracle.sobol_error_oracle import ClosedSobolWithErrorOracle, LiteralClosedSobolWithError
+    N, M = 30, 3
+    X, _ = o.synthetic_fold(N, M, k=3)
+    rng = np.random.default_rng(5)
+    ell = rng.uniform(0.7, 2.5, (L, M))
+    F = rng.uniform(0.8, 1.5, L)
+    noise = rng.uniform(0.01, 0.03, L)
+    Y = np.stack([o.synthetic_fold(N, M, k=3, l=l)[1] for l in range(L)], 1)
+    alpha = np.stack([o.k_inv_y(X, Y[:, l], ell[l], F[l], noise[l]) for l in range(L)])
+    Kc = np.stack([o.k_cho(X, ell[l], F[l], noise[l]) for l in range(L)])
+    lit = LiteralClosedSobolWithError(X, alpha[:, None, :], F[None, :], ell, Kc, is_T_partial=is_T_partial)
+    red = ClosedSobolWithErrorOracle(X, alpha[:, None, :], F[None, :], ell, Kc, is_T_partial=is_T_partial)
+    W_lit = lit.W if is_T_partial else lit.W.DIAGONAL
+    np.testing.assert_allclose(red.W, W_lit, rtol=1e-7)
+    if is_T_partial:
+        np.testing.assert_allclose(red.T, lit.T, rtol=1e-7)
+    else:
+        assert np.max(np.diag(lit.T)) < 1e-4 and np.max(np.diag(red.T)) < 1e-4      # the full model's own index has no error
+    for sl in [(0, 1), (0, 2), (1, 3), (2, 3), (1, 2)]:
+        a, b = lit.marginalize(sl), red.marginalize(sl)
+        np.testing.assert_allclose(b['W'], a['W'], rtol=1e-7)
+        np.testing.assert_allclose(b['T'], a['T'], rtol=1e-6, atol=1e-9)
+        assert np.all(a['T'] >= 0) and np.all(np.isfinite(a['T']))
