@@ -14,6 +14,7 @@
  *   rcgp_predict                  MOGP.predict -> gp.predict_y / predict_f (mean, SD)             gpr/models.py:375-384
  *   rcgp_sobol_closed             ClosedSobol._calibrate/_V/marginalize, diagonal (l = j) term    gsa/calibrators.py:49-97
  *   rcgp_sobol_cross              the same einsum's off-diagonal (l != j) entries                 gsa/calibrators.py:79
+ *   rcgp_sobol_error_terms        ClosedSobolWithError: mu_phi_mu, psi_factor, mu_psi_mu          gsa/calibrators.py:259-322
  *
  * Conventions: all matrices row-major float64; the caller owns every host buffer; the library owns device memory inside
  * the opaque handle until rcgp_destroy. A handle is bound to one device and one HIP stream; it is not thread-safe;
@@ -69,6 +70,17 @@ int rcgp_sobol_closed(rcgp_handle h, int n_slices, const int32_t* slices, double
  * alpha_j[N] = K_j^-1 y_j (from rcgp_get_k_inv_y of the other output, possibly gathered from another GPU). */
 int rcgp_sobol_cross(rcgp_handle h, const double* ell_j, double var_j, const double* alpha_j, int n_slices, const int32_t* slices,
                      double* V);
+
+/* Ingredients of the standard errors T, W of the Sobol indices (ClosedSobolWithError, gsa/calibrators.py:146-402) for the
+ * output pair (a, b): b = this handle's output (its Cholesky factor enters through psi_factor, :290-309); a = the same output
+ * when ell_a == alpha_a == NULL, else the output with lengthscales ell_a[M], kernel variance var_a and alpha_a[N] = K_a^-1 y_a.
+ * For every slice s (first-order [m,m+1), closed [0,m) or total-complement [m,M) only) four numbers, WITHOUT the doubling of
+ * a == b entries the reference applies (:281, :284, :322):
+ *   phi_d = mu_phi_mu term of the DIAGONAL rank equations (:259-288), psi_d = |psi_factor_ab|^2 (:311-322),
+ *   phi_m, psi_m = the same under the MIXED rank equation (used when is_T_partial is false).
+ * The caller assembles W = (phi - psi) + transpose and T (:324-346). Requires rcgp_factor; M <= 29. */
+int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var_a, const double* alpha_a, int n_slices, const int32_t* slices,
+                           double* phi_d, double* psi_d, double* phi_m, double* psi_m);
 
 /* ---- stage-level entry points used by bench.py and the kernel tests ---- */
 int rcgp_stage_gram(rcgp_handle h);      /* Z = X/ell; A = K + noise I (lower tiles) */

@@ -34,6 +34,8 @@ SIGNATURES = {
     'rcgp_predict': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]),
     'rcgp_sobol_closed': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int32_p, _c_double_p]),
     'rcgp_sobol_cross': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_int, _c_int32_p, _c_double_p]),
+    'rcgp_sobol_error_terms': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_int, _c_int32_p, _c_double_p,
+                                              _c_double_p, _c_double_p, _c_double_p]),
     'rcgp_stage_gram': (ctypes.c_int, [ctypes.c_void_p]),
     'rcgp_stage_potrf': (ctypes.c_int, [ctypes.c_void_p]),
     'rcgp_stage_trtri': (ctypes.c_int, [ctypes.c_void_p]),
@@ -204,6 +206,23 @@ class RcGP:
         self._check(self._lib.rcgp_sobol_cross(self._h, _dp(ell_j), float(var_j), _dp(alpha_j), s.shape[0],
                                                s.ctypes.data_as(_c_int32_p), _dp(V)), 'rcgp_sobol_cross')
         return V
+
+    def sobol_error_terms(self, slices, ell_a=None, var_a: float = 0.0, alpha_a=None):
+        """(phi_d, psi_d, phi_m, psi_m), each (n_slices,), for the output pair (a, b = this handle); a = b when ``ell_a`` is None."""
+        s = self._slices(slices)
+        n = s.shape[0]
+        out = [np.empty(n) for _ in range(4)]
+        if ell_a is None:
+            ell_p, alpha_p = None, None
+        else:
+            ell_a = np.ascontiguousarray(np.broadcast_to(np.asarray(ell_a, dtype=np.float64).reshape(-1), (self.M,)))
+            alpha_a = _f64(alpha_a).reshape(-1)
+            if alpha_a.shape[0] != self.N:
+                raise ValueError('alpha_a must have N entries')
+            ell_p, alpha_p = _dp(ell_a), _dp(alpha_a)
+        self._check(self._lib.rcgp_sobol_error_terms(self._h, ell_p, float(var_a), alpha_p, n, s.ctypes.data_as(_c_int32_p),
+                                                     *[_dp(o) for o in out]), 'rcgp_sobol_error_terms')
+        return tuple(out)
 
     # -- stages and profiling (bench / kernel tests)
     def stage_gram(self):

@@ -300,6 +300,20 @@ __global__ void __launch_bounds__(256) k_rowdot(const double* __restrict__ KsT, 
   if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
 
+int rc_ensure_pred(rcgp_handle_s* h) {
+  if (h->KsT) return 0;
+  const int M = h->M;
+  const int64_t Np = h->Np;
+  RC_HIP(hipMalloc(&h->Xs, (size_t)PRED_CAP * M * sizeof(double)));
+  RC_HIP(hipMalloc(&h->Zs, (size_t)PRED_CAP * M * sizeof(double)));
+  RC_HIP(hipMalloc(&h->sqs, (size_t)PRED_CAP * sizeof(double)));
+  RC_HIP(hipMalloc(&h->KsT, (size_t)PRED_CAP * Np * sizeof(double)));
+  RC_HIP(hipMalloc(&h->pmean, (size_t)PRED_CAP * sizeof(double)));
+  RC_HIP(hipMalloc(&h->pvar, (size_t)PRED_CAP * sizeof(double)));
+  h->pred_cap = PRED_CAP;
+  return 0;
+}
+
 RC_API int rcgp_predict(rcgp_handle h, int64_t n, const double* Xnew, int include_noise, double* mean, double* sd) {
   RC_CHECK_H(h);
   if (n < 0 || (n > 0 && (!Xnew || !mean || !sd))) { h->err = "rcgp_predict: bad argument"; return -2; }
@@ -307,15 +321,7 @@ RC_API int rcgp_predict(rcgp_handle h, int64_t n, const double* Xnew, int includ
   if ((rc = rcgp_factor(h))) return rc;
   const int M = h->M;
   const int64_t Np = h->Np;
-  if (!h->KsT) {
-    RC_HIP(hipMalloc(&h->Xs, (size_t)PRED_CAP * M * sizeof(double)));
-    RC_HIP(hipMalloc(&h->Zs, (size_t)PRED_CAP * M * sizeof(double)));
-    RC_HIP(hipMalloc(&h->sqs, (size_t)PRED_CAP * sizeof(double)));
-    RC_HIP(hipMalloc(&h->KsT, (size_t)PRED_CAP * Np * sizeof(double)));
-    RC_HIP(hipMalloc(&h->pmean, (size_t)PRED_CAP * sizeof(double)));
-    RC_HIP(hipMalloc(&h->pvar, (size_t)PRED_CAP * sizeof(double)));
-    h->pred_cap = PRED_CAP;
-  }
+  if ((rc = rc_ensure_pred(h))) return rc;
   std::vector<double> hv(PRED_CAP);
   for (int64_t o0 = 0; o0 < n; o0 += PRED_CAP) {
     const int64_t nc = (n - o0 < PRED_CAP) ? n - o0 : PRED_CAP;
@@ -358,6 +364,21 @@ RC_API int rcgp_sobol_cross(rcgp_handle h, const double* ell_j, double var_j, co
   int rc;
   if ((rc = rcgp_factor(h))) return rc;
   return rc_sobol(h, ell_j, var_j, alpha_j, n_slices, slices, V);
+}
+
+RC_API int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var_a, const double* alpha_a, int n_slices,
+                                  const int32_t* slices, double* phi_d, double* psi_d, double* phi_m, double* psi_m) {
+  RC_CHECK_H(h);
+  if (n_slices < 0 || (n_slices > 0 && (!slices || !phi_d || !psi_d || !phi_m || !psi_m)) || ((ell_a == nullptr) != (alpha_a == nullptr))) {
+    h->err = "rcgp_sobol_error_terms: bad argument";
+    return -2;
+  }
+  if (ell_a)
+    for (int m = 0; m < h->M; ++m)
+      if (!(ell_a[m] > 0.0)) { h->err = "rcgp_sobol_error_terms: lengthscales must be positive"; return -2; }
+  int rc;
+  if ((rc = rcgp_factor(h))) return rc;
+  return rc_sobol_error_terms(h, ell_a, var_a, alpha_a, n_slices, slices, phi_d, psi_d, phi_m, psi_m);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -139,6 +139,10 @@ int rc_grad_finish(rcgp_handle_s* h, int nrows, double* grad);
 int rc_sobol(rcgp_handle_s* h, const double* ell_j, double var_j, const double* alpha_j_host, int n_slices, const int32_t* slices,
              double* V_host);
 
+int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, const double* alpha_a_host, int n_slices,
+                         const int32_t* slices, double* phi_d, double* psi_d, double* phi_m, double* psi_m);
+
 // ---- util
+int rc_ensure_pred(rcgp_handle_s* h);                        // predict / psi scratch (KsT, pvar, ...)
 int rc_ensure_partial(rcgp_handle_s* h, size_t elems);
 int rc_prof_collect(rcgp_handle_s* h);

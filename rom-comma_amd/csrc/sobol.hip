@@ -8,24 +8,27 @@
 // VALU-bound (fp64 exp), traffic ~ 2 N M doubles per tile from L2: no HBM roofline applies.
 #include "common.h"
 #include "rc_math.h"
+#include <limits>
 
 #define XST 130
 
 // graw[i] = pre * exp(-1/2 sum_m phi_m x_im^2) * alpha_i   (gsa/calibrators.py:86-89); padded rows -> 0
 __global__ void k_sobol_g0(const double* __restrict__ X, const double* __restrict__ alpha, const double* __restrict__ phi, double pre,
-                           int64_t N, int64_t Np, int M, double* __restrict__ g) {
+                           int64_t N, int64_t Np, int M, double* __restrict__ g, double* __restrict__ g0_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Np) return;
-  double v = 0.0;
+  double v = 0.0, v0 = 0.0;
   if (i < N) {
     double s = 0.0;
     for (int m = 0; m < M; ++m) {
       const double x = X[i * M + m];
       s = fma(phi[m] * x, x, s);
     }
-    v = pre * rc_exp(-0.5 * s) * alpha[i];
+    v0 = pre * rc_exp(-0.5 * s);
+    v = v0 * alpha[i];
   }
   g[i] = v;
+  if (g0_out) g0_out[i] = v0;
 }
 
 __global__ void __launch_bounds__(1024) k_sum1(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(256) k_rowreduce_s(const double* __restrict__ 
 }
 
 static int sobol_make_g(rcgp_handle_s* h, const double* ell, double var, const double* alpha_d, double* phi_d, double* g_d,
-                        double* sum_d, std::vector<double>& phi_host) {
+                        double* sum_d, std::vector<double>& phi_host, double* g0_d = nullptr) {
   const int M = h->M;
   phi_host.resize(M);
   double pre = var;
@@ -228,7 +231,7 @@ static int sobol_make_g(rcgp_handle_s* h, const double* ell, double var, const d
   RC_HIP(hipStreamSynchronize(h->stream));               // phi_host may be reused by the caller
   RcProfScope ps(h, RC_K_MISC, 0.0);
   const unsigned nb = (unsigned)((h->Np + 255) / 256);
-  hipLaunchKernelGGL(k_sobol_g0, dim3(nb), dim3(256), 0, h->stream, h->X, alpha_d, phi_d, pre, h->N, h->Np, M, g_d);
+  hipLaunchKernelGGL(k_sobol_g0, dim3(nb), dim3(256), 0, h->stream, h->X, alpha_d, phi_d, pre, h->N, h->Np, M, g_d, g0_d);
   hipLaunchKernelGGL(k_sum1, dim3(1), dim3(1024), 0, h->stream, g_d, h->N, sum_d);
   hipLaunchKernelGGL(k_sobol_center, dim3(nb), dim3(256), 0, h->stream, g_d, h->N, sum_d);
   hipLaunchKernelGGL(k_sum1, dim3(1), dim3(1024), 0, h->stream, g_d, h->N, sum_d + 1);
@@ -331,6 +334,371 @@ int rc_sobol(rcgp_handle_s* h, const double* ell_j, double var_j, const double* 
       std::vector<double> one;
       if ((rc = run(1, a, b, one))) return rc;
       V_host[s] = one[0];
+    }
+  }
+  return 0;
+}
+
+// =====================================================================================================================
+// Standard errors of the Sobol indices (reference gsa/calibrators.py:146-402, ClosedSobolWithError). DESIGN.md
+// "Sobol error algebra": for an output pair (a, b) every ingredient is either
+//   (1) a pair quadratic form  sum_{N,n} gA[N] gB[n] exp(sum_{m in S} c0 + cN x_N^2 + cn x_n^2 + cx x_N x_n)   -> k_sobol_pairs
+//   (2) a pair matrix-vector   u_S[n] = sum_N g_a[N] H^S_ab(N,n)                                                   -> k_sobol_matvec
+//   (3) |L_b^-1 f|^2 for f_S = g0_b * u_S                                                                          -> k_predict_var
+// with per-dimension coefficients computed on the host.
+// =====================================================================================================================
+
+// u partials: partial[(ti * 3M + s) * Np + n] = sum over the rows of row-tile ti of gl[N] * prod_{m in slice s} h_m(N, n), for
+// the canonical slices (first-order m, closed [0,m+1), complement [m+1,M)). Same tile/thread layout as k_sobol_pairs.
+__global__ void __launch_bounds__(256) k_sobol_matvec(const double* __restrict__ X, const double* __restrict__ gl,
+                                                      const double* __restrict__ consts, int M, int64_t Np, double* __restrict__ partial) {
+  extern __shared__ double sm[];
+  double* xi = sm;                        // [M][XST] rows (N side)
+  double* xj = sm + M * XST;              // [M][XST] columns (n side)
+  double* slots = xj + M * XST;           // [4 waves][2 kinds][128]
+  double* colacc = slots + 4 * 2 * 128;   // [3M][128]
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int e = t; e < 128 * M; e += 256) {
+    const int rr = e / M, m = e - rr * M;
+    xi[m * XST + rr] = X[((int64_t)ti * 128 + rr) * M + m];
+    xj[m * XST + rr] = X[((int64_t)tj * 128 + rr) * M + m];
+  }
+  for (int e = t; e < 3 * M * 128; e += 256) colacc[e] = 0.0;
+  const int tx = t & 15, ty = t >> 4;
+  double gi[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) gi[a] = gl[(int64_t)ti * 128 + ty + 16 * a];
+  __syncthreads();
+  const double* c0 = consts;
+  const double* c2 = consts + M;
+  const double* pl = consts + 2 * M;
+  const double* pj = consts + 3 * M;
+  double e[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) e[a][c] = 0.0;
+
+  // one m-step: computes t_m, updates the running sums, returns per-column partial sums over this thread's rows
+  auto publish = [&](const double (&cf)[8], const double (&cc)[8], int nkinds, int idx0, int idx1) {
+    // reduce over the 4 row-groups of the wave (lanes differing in lane >> 4), then one slot per wave
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      double vf = cf[c], vc = cc[c];
+      vf += __shfl_xor(vf, 16);
+      vf += __shfl_xor(vf, 32);
+      if (nkinds > 1) {
+        vc += __shfl_xor(vc, 16);
+        vc += __shfl_xor(vc, 32);
+      }
+      if ((lane >> 4) == 0) {
+        const int col = 2 * tx + 32 * (c >> 1) + (c & 1);
+        slots[(wave * 2 + 0) * 128 + col] = vf;
+        if (nkinds > 1) slots[(wave * 2 + 1) * 128 + col] = vc;
+      }
+    }
+    __syncthreads();
+    if (t < 128 * nkinds) {
+      const int kind = t >> 7, col = t & 127;
+      const double sum = (slots[(0 * 2 + kind) * 128 + col] + slots[(1 * 2 + kind) * 128 + col]) +
+                         (slots[(2 * 2 + kind) * 128 + col] + slots[(3 * 2 + kind) * 128 + col]);
+      colacc[(kind == 0 ? idx0 : idx1) * 128 + col] += sum;          // a single owner thread per (slice, column): fixed order
+    }
+    __syncthreads();
+  };
+
+  for (int m = 0; m < M; ++m) {                                       // ascending: first-order [m,m+1) and closed [0,m+1)
+    const double k0 = c0[m], k2 = c2[m], kl = pl[m], kj = pj[m];
+    double ai[8], ui[8], bj[8], xc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const double x = xi[m * XST + ty + 16 * a];
+      ai[a] = fma(kl * x, x, k0);
+      ui[a] = k2 * x;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const double2 x = *reinterpret_cast<const double2*>(xj + m * XST + 2 * tx + 32 * b);
+      xc[2 * b] = x.x;
+      xc[2 * b + 1] = x.y;
+      bj[2 * b] = kj * x.x * x.x;
+      bj[2 * b + 1] = kj * x.y * x.y;
+    }
+    double cf[8], cc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { cf[c] = 0.0; cc[c] = 0.0; }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const double tm = fma(ui[a], xc[c], ai[a] + bj[c]);
+        e[a][c] += tm;
+        cf[c] = fma(gi[a], rc_exp(tm), cf[c]);
+        cc[c] = fma(gi[a], rc_exp(e[a][c]), cc[c]);
+      }
+    publish(cf, cc, 2, m, M + m);
+  }
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) e[a][c] = 0.0;
+  for (int m = M - 1; m >= 1; --m) {                                  // descending: complements [m, M) -> index 2M + m - 1
+    const double k0 = c0[m], k2 = c2[m], kl = pl[m], kj = pj[m];
+    double ai[8], ui[8], bj[8], xc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const double x = xi[m * XST + ty + 16 * a];
+      ai[a] = fma(kl * x, x, k0);
+      ui[a] = k2 * x;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const double2 x = *reinterpret_cast<const double2*>(xj + m * XST + 2 * tx + 32 * b);
+      xc[2 * b] = x.x;
+      xc[2 * b + 1] = x.y;
+      bj[2 * b] = kj * x.x * x.x;
+      bj[2 * b + 1] = kj * x.y * x.y;
+    }
+    double cf[8], cc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { cf[c] = 0.0; cc[c] = 0.0; }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        e[a][c] += fma(ui[a], xc[c], ai[a] + bj[c]);
+        cf[c] = fma(gi[a], rc_exp(e[a][c]), cf[c]);
+      }
+    publish(cf, cc, 1, 2 * M + m - 1, 0);
+  }
+  for (int idx = t; idx < 3 * M * 128; idx += 256) {
+    const int s = idx >> 7, col = idx & 127;
+    partial[((int64_t)ti * 3 * M + s) * Np + (int64_t)tj * 128 + col] = colacc[idx];
+  }
+}
+
+__global__ void k_reduce_rows(const double* __restrict__ partial, int64_t rows, int64_t n, double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s = 0.0;
+  for (int64_t r = 0; r < rows; ++r) s += partial[r * n + j];
+  out[j] = s;
+}
+
+// g~[N] = g[N] * exp(sum_m cu_m x_Nm^2 + c)   (the full-model Upsilon factor of the MIXED rank equation)
+__global__ void k_sobol_gtilde(const double* __restrict__ X, const double* __restrict__ g, const double* __restrict__ cu, double cadd,
+                               int64_t N, int64_t Np, int M, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Np) return;
+  double v = 0.0;
+  if (i < N) {
+    double s = cadd;
+    for (int m = 0; m < M; ++m) {
+      const double x = X[i * M + m];
+      s = fma(cu[m] * x, x, s);
+    }
+    v = g[i] * rc_exp(s);
+  }
+  out[i] = v;
+}
+
+// F rows for the psi terms (row-major [rows][Np] into KsT): r < 3M: g0 * u_r ; 3M <= r < 6M: g0 * (u_{r-3M} + u_full) ;
+// r == 6M: g0 * u_full_bb (the (b,b) full-model vector when a != b, else a copy of row `full`) ; zero beyond.
+__global__ void k_sobol_psi_rows(const double* __restrict__ U, const double* __restrict__ Ufull, const double* __restrict__ g0,
+                                 int M, int64_t Np, int64_t rows_padded, double* __restrict__ F) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (n >= Np) return;
+  double v = 0.0;
+  if (r < 3 * M) v = g0[n] * U[(int64_t)r * Np + n];
+  else if (r < 6 * M) v = g0[n] * (U[(int64_t)(r - 3 * M) * Np + n] + Ufull[n]);
+  else if (r == 6 * M) v = g0[n] * Ufull[n];
+  F[(int64_t)r * Np + n] = v;
+}
+
+int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, const double* alpha_a_host, int n_slices,
+                         const int32_t* slices, double* phi_d_out, double* psi_d_out, double* phi_m_out, double* psi_m_out) {
+  const int M = h->M;
+  const int64_t Np = h->Np, T = Np / 128;
+  const bool self = (ell_a == nullptr);
+  if (M > 29) { h->err = "sobol errors: at most 29 input dimensions are supported"; return -6; }
+  for (int s = 0; s < n_slices; ++s) {
+    const int a = slices[2 * s], b = slices[2 * s + 1];
+    if (a < 0 || b > M || a > b) { h->err = "sobol errors: bad slice"; return -2; }
+    if (!(a == b || b == a + 1 || a == 0 || b == M)) { h->err = "sobol errors: only first-order, closed and total slices are supported"; return -6; }
+  }
+  int rc;
+  if ((rc = rc_ensure_pred(h))) return rc;
+  // scratch: g_b g0_b g_a alpha_a g~_b [5 Np] | U [3M Np] | Ubb_full... we keep a second U for the (b,b) pass when a != b
+  const size_t need = (size_t)5 * Np + (size_t)2 * 3 * M * Np + 16 * M + 16;
+  if (h->sob_elems < need) {
+    if (h->sob) { RC_HIP(hipStreamSynchronize(h->stream)); RC_HIP(hipFree(h->sob)); h->sob = nullptr; }
+    RC_HIP(hipMalloc(&h->sob, need * sizeof(double)));
+    h->sob_elems = need;
+  }
+  double* g_b = h->sob;
+  double* g0_b = g_b + Np;
+  double* g_a = g0_b + Np;
+  double* al_a = g_a + Np;
+  double* gt_b = al_a + Np;
+  double* U = gt_b + Np;
+  double* Ubb = U + (size_t)3 * M * Np;
+  double* small = Ubb + (size_t)3 * M * Np;            // phi_b[M] phi_a[M] consts[4M] cu[M] sums[8]
+  double* phi_b_d = small;
+  double* phi_a_d = small + M;
+  double* consts_d = small + 2 * M;
+  double* cu_d = small + 6 * M;
+  double* sums_d = small + 7 * M;
+  std::vector<double> phi_b, phi_a;
+  if ((rc = sobol_make_g(h, h->ell.data(), h->var, h->alpha, phi_b_d, g_b, sums_d, phi_b, g0_b))) return rc;
+  if (!self) {
+    RC_HIP(hipMemsetAsync(al_a, 0, (size_t)Np * sizeof(double), h->stream));
+    RC_HIP(hipMemcpyAsync(al_a, alpha_a_host, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if ((rc = sobol_make_g(h, ell_a, var_a, al_a, phi_a_d, g_a, sums_d + 2, phi_a))) return rc;
+  } else {
+    phi_a = phi_b;
+    g_a = g_b;
+  }
+  std::vector<double> ups_b(M);
+  double pre_b = h->var;
+  for (int m = 0; m < M; ++m) {
+    const double l2 = h->ell[m] * h->ell[m];
+    ups_b[m] = 1.0 / (l2 + 2.0);
+    pre_b *= sqrt(l2 * ups_b[m]);                                  // gsa/calibrators.py:384
+  }
+  // host coefficient sets, kernel order [c0 | c2 (cross) | pl (row side, x_N^2) | pj (column side, x_n^2)]
+  auto coeffs = [&](char kind, const std::vector<double>& pa, const std::vector<double>& pb, std::vector<double>& out) {
+    out.resize(4 * M);
+    for (int m = 0; m < M; ++m) {
+      const double fa = pa[m], fb = pb[m], ub = ups_b[m], ga = 1.0 - fa, gb = 1.0 - fb;
+      double k0, kN, kn, kx;
+      if (kind == 'H') {
+        const double aa = fa * fb, c2 = aa / (1.0 - aa);
+        k0 = -0.5 * log1p(-aa); kN = -0.5 * c2 * fa; kn = -0.5 * c2 * fb; kx = c2;
+      } else {
+        const double Pi = 1.0 / (1.0 + fb + fb * fb / gb);
+        const double B = ga * fa + fa * fa * Pi;
+        const double Om = fa * Pi * fb / gb;
+        if (kind == 'D') {
+          const double C = ga * (1.0 - ub) / (1.0 - fa * ub), mu = Om * C * fa / ga, Var = B + Om * Om * C, den = 1.0 - ub * fa;
+          k0 = 0.5 * log(fa / Var) - 0.5 * log(den);
+          kN = -0.5 * mu * mu / Var - 0.5 * ub * fa * fa / den;
+          kn = -0.5 * fa * fa / Var + 0.5 * fa;
+          kx = mu * fa / Var;
+        } else {
+          const double C = gb * (1.0 - ub) / (1.0 - fb * ub), mu = Om * C * fb / gb, Var = B + Om * Om * C;
+          k0 = 0.5 * log(fa / Var);
+          kN = -0.5 * mu * mu / Var;
+          kn = -0.5 * fa * fa / Var + 0.5 * fa;
+          kx = mu * fa / Var;
+        }
+      }
+      out[m] = k0; out[M + m] = kx; out[2 * M + m] = kN; out[3 * M + m] = kn;
+    }
+  };
+  const int64_t nblk = T * T;
+  const size_t lds_pairs = (size_t)(2 * M * XST + 4 * 3 * M) * sizeof(double);
+  const size_t lds_mv = (size_t)(2 * M * XST + 4 * 2 * 128 + 3 * M * 128) * sizeof(double);
+  RC_HIP(hipFuncSetAttribute((const void*)k_sobol_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
+  RC_HIP(hipFuncSetAttribute((const void*)k_sobol_matvec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mv));
+  const double pairs = (double)h->N * (double)h->N;
+  double* out_d = sums_d + 8;                                   // not used (reductions write into small scratch below)
+  (void)out_d;
+
+  auto pair_pass = [&](const std::vector<double>& c, const double* gl, const double* gj, std::vector<double>& out) -> int {
+    int r = rc_ensure_partial(h, (size_t)nblk * 3 * M);
+    if (r) return r;
+    RC_HIP(hipMemcpyAsync(consts_d, c.data(), (size_t)4 * M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    {
+      RcProfScope ps(h, RC_K_SOBOL, pairs * (double)(3 * M - 1));
+      hipLaunchKernelGGL(k_sobol_pairs<false>, dim3((unsigned)T, (unsigned)T), dim3(256), lds_pairs, h->stream, h->X, gl, gj, consts_d, M, 0, 0,
+                         M, h->partial);
+      RC_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_rowreduce_s, dim3((unsigned)(3 * M)), dim3(256), 0, h->stream, h->partial, nblk, 3 * M, U);   // U reused as tiny out
+    RC_HIP(hipGetLastError());
+    out.resize(3 * M);
+    RC_HIP(hipMemcpyAsync(out.data(), U, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RC_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+  };
+  auto matvec_pass = [&](const std::vector<double>& c, const double* gl, double* Uout) -> int {
+    int r = rc_ensure_partial(h, (size_t)T * 3 * M * Np);
+    if (r) return r;
+    RC_HIP(hipMemcpyAsync(consts_d, c.data(), (size_t)4 * M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    {
+      RcProfScope ps(h, RC_K_SOBOL, pairs * (double)(3 * M - 1));
+      hipLaunchKernelGGL(k_sobol_matvec, dim3((unsigned)T, (unsigned)T), dim3(256), lds_mv, h->stream, h->X, gl, consts_d, M, Np, h->partial);
+      RC_HIP(hipGetLastError());
+    }
+    const int64_t n = (int64_t)3 * M * Np;
+    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->partial, T, n, Uout);
+    RC_HIP(hipGetLastError());
+    return 0;
+  };
+
+  std::vector<double> cD, cM, cH, canonD, canonM;
+  coeffs('D', phi_a, phi_b, cD);
+  coeffs('M', phi_a, phi_b, cM);
+  coeffs('H', phi_a, phi_b, cH);
+  // (1) DIAGONAL quadratic form: g_a on both sides
+  if ((rc = pair_pass(cD, g_a, g_a, canonD))) return rc;
+  // (2) MIXED quadratic form: g~_b on the row side, g_a on the column side
+  {
+    std::vector<double> cu(M);
+    double cadd = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const double den = 1.0 - ups_b[m] * phi_b[m];
+      cu[m] = -0.5 * ups_b[m] * phi_b[m] * phi_b[m] / den;
+      cadd -= 0.5 * log(den);
+    }
+    RC_HIP(hipMemcpyAsync(cu_d, cu.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC_HIP(hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(k_sobol_gtilde, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, h->stream, h->X, g_b, cu_d, cadd, h->N, Np, M, gt_b);
+    RC_HIP(hipGetLastError());
+  }
+  if ((rc = pair_pass(cM, gt_b, g_a, canonM))) return rc;
+  // (3) psi terms
+  if ((rc = matvec_pass(cH, g_a, U))) return rc;
+  const int full = 2 * M - 1;                                     // closed [0, M)
+  const double* Ufull_bb = U + (size_t)full * Np;
+  if (!self) {
+    std::vector<double> cHbb;
+    coeffs('H', phi_b, phi_b, cHbb);
+    if ((rc = matvec_pass(cHbb, g_b, Ubb))) return rc;
+    Ufull_bb = Ubb + (size_t)full * Np;
+  }
+  const int64_t rows = 6 * M + 1, rows_padded = ((rows + 127) / 128) * 128;
+  hipLaunchKernelGGL(k_sobol_psi_rows, dim3((unsigned)((Np + 255) / 256), (unsigned)rows_padded), dim3(256), 0, h->stream, U, Ufull_bb, g0_b, M,
+                     Np, rows_padded, h->KsT);
+  RC_HIP(hipGetLastError());
+  if ((rc = rc_launch_predict_var(h, rows_padded))) return rc;
+  std::vector<double> pv(rows_padded);
+  RC_HIP(hipMemcpyAsync(pv.data(), h->pvar, (size_t)rows_padded * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  // NOTE rows 3M..6M-1 hold u_S + u_full of the (a,b) pass; the mixed term needs psi_full of (b,b): for a == b they coincide.
+  for (int s = 0; s < n_slices; ++s) {
+    const int a = slices[2 * s], b = slices[2 * s + 1];
+    if (a == b) { phi_d_out[s] = psi_d_out[s] = phi_m_out[s] = psi_m_out[s] = 0.0; continue; }
+    const int idx = (a == 0) ? M + (b - 1) : ((b == M) ? 2 * M + (a - 1) : a);
+    phi_d_out[s] = pre_b * canonD[idx];
+    phi_m_out[s] = pre_b * canonM[idx];
+    psi_d_out[s] = pv[idx];
+    if (self) {
+      psi_m_out[s] = 0.5 * (pv[3 * M + idx] - pv[idx] - pv[full]);
+    } else {
+      psi_m_out[s] = std::numeric_limits<double>::quiet_NaN();     // filled by the second GEMM below
+    }
+  }
+  if (!self) {
+    // psi_full(b,b) . psi_S(a,b) by polarisation with rows g0 * (u_S + u_full_bb): rebuild rows 3M.. with Ufull_bb (already the
+    // case: k_sobol_psi_rows adds Ufull = Ufull_bb), and |psi_full_bb|^2 is row 6M.
+    for (int s = 0; s < n_slices; ++s) {
+      const int a = slices[2 * s], b = slices[2 * s + 1];
+      if (a == b) continue;
+      const int idx = (a == 0) ? M + (b - 1) : ((b == M) ? 2 * M + (a - 1) : a);
+      psi_m_out[s] = 0.5 * (pv[3 * M + idx] - pv[idx] - pv[6 * M]);
     }
   }
   return 0;

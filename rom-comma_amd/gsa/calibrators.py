@@ -85,13 +85,77 @@ class ClosedSobol(Calibrator):
 
 
 class ClosedSobolWithError(ClosedSobol):
-    """Standard errors T, W of the indices (reference gsa/calibrators.py:146-402): SURVEY.md 8f rank 2, not built yet."""
+    """Closed Sobol indices with their standard errors T and the covariances W behind them (reference
+    gsa/calibrators.py:146-402). The reference builds rank-7 tensors under "rank equations"; algebraically ("Sobol
+    error algebra"; checked against a literal transliteration in tests/test_oracle.py) every entry (a, b) of
+
+        mu_phi_mu (:259-288)  = (1 + delta_ab) phi[a, b]        mu_psi_mu (:311-322) = (1 + delta_ab) psi[a, b]
+
+    comes from O(N^2) pair sums and one |L_b^-1 f|^2, which ``rcgp_sobol_error_terms`` evaluates on the GPU for all
+    first-order / closed / total slices at once. This class assembles W = (mu_phi_mu - mu_psi_mu) + transpose (:324-331) and
+    T (:333-346) exactly as the reference does, for the DIAGONAL rank equations and, when ``is_T_partial`` is False, the MIXED one.
+    """
 
     @classmethod
     @property
     def META(cls) -> Dict[str, Any]:
         return {'is_T_partial': True}
 
-    def __init__(self, gp: GPR, **kwargs: Any):
-        raise NotImplementedError('ClosedSobolWithError (index standard errors T, W) is not implemented on this backend yet; '
-                                  'run with is_error_calculated=False')
+    def _error_matrices(self, slices: Sequence[Tuple[int, int]]) -> None:
+        """Fill the caches W_diag[slice], W_mixed[slice] (L, L) for the given slices."""
+        slices = [s for s in dict.fromkeys((int(a), int(b)) for a, b in slices) if s not in self._W_diag]
+        if not slices:
+            return
+        L = self.L
+        D = np.zeros((L, L, len(slices)))
+        Mx = np.zeros((L, L, len(slices)))
+        for b in range(L):
+            handle = self.gp._select(b)
+            for a in range(L):
+                if a == b:
+                    phi_d, psi_d, phi_m, psi_m = handle.sobol_error_terms(slices)
+                else:
+                    phi_d, psi_d, phi_m, psi_m = handle.sobol_error_terms(slices, self.Lambda[a], self.F[a], self.K_inv_Y[a])
+                doubled = 2.0 if a == b else 1.0                       # set_diag(2 * diag): gsa/calibrators.py:281,284,322
+                D[a, b] = doubled * (phi_d - psi_d)
+                Mx[a, b] = doubled * (phi_m - psi_m)
+        for i, s in enumerate(slices):
+            self._W_diag[s] = D[..., i] + D[..., i].T                  # _W: W += transpose(W)  (:324-331)
+            self._W_mixed[s] = Mx[..., i] + Mx[..., i].T
+
+    def _T(self, Wmm: np.ndarray, WMm: np.ndarray = None, Vm: np.ndarray = None) -> np.ndarray:
+        """The index uncertainty (gsa/calibrators.py:333-346)."""
+        if self.meta['is_T_partial']:
+            Q = Wmm
+        else:
+            Q = Wmm - 2 * Vm * WMm / self.V[1] + Vm * Vm * self.Q
+        return np.sqrt(np.abs(Q) / self.V[4])
+
+    def _calibrate(self):
+        super()._calibrate()
+        if not self.is_F_diagonal:
+            raise NotImplementedError('If the MOGP kernel covariance is not diagonal, the Sobol error calculation is unstable.')
+        M = self.M
+        self._W_diag: Dict[Tuple[int, int], np.ndarray] = {}
+        self._W_mixed: Dict[Tuple[int, int], np.ndarray] = {}
+        self.V[4] = self.V[2] * self.V[2]                              # :383
+        canonical = [(m, m + 1) for m in range(M)] + [(0, m + 1) for m in range(M)] + [(m + 1, M) for m in range(M)]
+        self._error_matrices(canonical)
+        full = (0, M)
+        if self.meta['is_T_partial']:
+            self.W = self._W_diag[full]
+            self.T = self._T(self.W)
+        else:
+            self.W = {'DIAGONAL': self._W_diag[full], 'MIXED': self._W_mixed[full]}
+            q = np.diagonal(self._W_mixed[full]) / (4.0 * self.V[1] * self.V[1])                       # :400-401
+            self.Q = q[None, :] + q[:, None] + 2.0 * np.diag(q)
+            self.T = self._T(self._W_diag[full], self._W_mixed[full], self.V[0])
+
+    def marginalize(self, m) -> Dict[str, np.ndarray]:
+        """{'V', 'S', 'W', 'T'} for the slice [m[0], m[1]) (gsa/calibrators.py:348-373)."""
+        result = super().marginalize(m)
+        key = (int(m[0]), int(m[1]))
+        self._error_matrices([key])
+        Wmm = self._W_diag[key]
+        result |= {'W': Wmm, 'T': self._T(Wmm, self._W_mixed[key], result['V'])}
+        return result

@@ -139,4 +139,8 @@ class Sobol(GSA):
         if self.kind == GSA.Kind.TOTAL:
             results['S'] = calibrator.S[..., None] - results['S']
         results['S'] = np.concatenate([results['S'], calibrator.S[..., None]], axis=-1)
+        if 'T' in results and not self.meta['is_T_partial']:
+            if self.kind == GSA.Kind.TOTAL:
+                results['T'] = calibrator.T[..., None] + results['T']
+            results['T'] = np.concatenate([results['T'], calibrator.T[..., None]], axis=-1)
         return results

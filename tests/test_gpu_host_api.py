@@ -85,6 +85,26 @@ def test_run_gpr_gsa_end_to_end(gpu, tmp_path):
     first = Sobol(gp, GSA.Kind.FIRST_ORDER, m=1)
     first.calibrate()
     assert first.results['S'].shape == (2, 2, 2) and first.folder.name == 'first_order.1'
-    with pytest.raises(NotImplementedError):
-        Sobol(gp, GSA.Kind.CLOSED, is_error_calculated=True).calibrate()
+    # ---- standard errors (ClosedSobolWithError): partial and full T, all kinds, against the reduced-form oracle
+    from oracle.sobol_error_oracle import ClosedSobolWithErrorOracle
+    Kc = np.stack([o.k_cho(X, Y[:, l], ell[l], var[l], noise[l]) if False else o.k_cho(X, ell[l], var[l], noise[l]) for l in range(2)])
+    for partial in (True, False):
+        err = ClosedSobolWithErrorOracle(X, alpha[:, None, :], var[None, :], ell, Kc, is_T_partial=partial)
+        for kind, okind in ((GSA.Kind.FIRST_ORDER, o.FIRST_ORDER), (GSA.Kind.CLOSED, o.CLOSED), (GSA.Kind.TOTAL, o.TOTAL)):
+            sobol = Sobol(gp, kind, is_error_calculated=True, is_T_partial=partial)
+            sobol.calibrate()
+            per_slice = [err.marginalize(sl) for sl in o.gsa_slices(okind, 3)]
+            W = np.stack([r['W'] for r in per_slice], axis=-1)
+            T = np.stack([r['T'] for r in per_slice], axis=-1)
+            if not partial:                                              # gsa/models.py:211-213
+                T = np.concatenate([err.T[..., None] + T if okind == o.TOTAL else T, err.T[..., None]], axis=-1)
+            # W = mu_phi_mu - mu_psi_mu cancels heavily for irrelevant inputs: absolute tolerance relative to the largest entry
+            np.testing.assert_allclose(sobol.results['W'], W, rtol=1e-5, atol=1e-6 * np.max(np.abs(W)))
+            np.testing.assert_allclose(sobol.results['T'], T, rtol=1e-4, atol=1e-3 * np.max(np.abs(T)))   # T_full ~ sqrt(cancellation noise)
+            assert sobol.results['T'].shape == (2, 2, 3 if partial else 4)
+            assert (sobol.folder / 'T.csv').exists() and (sobol.folder / 'W.csv').exists()
     gp.close()
+    names = run.gsa('gpr', repo, is_covariant=False, is_isotropic=False, kinds=GSA.Kind.CLOSED, is_error_calculated=True, is_T_partial=False)
+    assert [str(n) for n in names] == ['gpr.v.a/gsa/closed']
+    collected = pd.read_csv(repo.folder / 'gpr.v.a' / 'gsa' / 'closed' / 'T.csv')
+    assert list(collected.columns[:2]) == ['N', 'fold'] and collected.shape[0] == 2 * 4

@@ -248,3 +248,33 @@ def test_full_size_properties(gpu, N, M):
     total = 1.0 - comp / full
     assert np.all(total >= first / full - 1e-7)
     gp.close()
+
+
+@pytest.mark.parametrize('L', [1, 2])
+def test_sobol_error_terms(gpu, L):
+    """rcgp_sobol_error_terms against the reduced-form oracle (itself checked against the literal transliteration of
+    ClosedSobolWithError): the four ingredients per slice and output pair, at a ragged N."""
+    from oracle import sobol_error_oracle as e
+    N, M = 333, 4
+    X, _ = o.synthetic_fold(N, M, k=2)
+    rng = np.random.default_rng(11)
+    ell = rng.uniform(0.7, 2.5, (L, M))
+    F = rng.uniform(0.8, 1.5, L)
+    noise = rng.uniform(0.01, 0.03, L)
+    Y = np.stack([o.synthetic_fold(N, M, k=2, l=l)[1] for l in range(L)], 1)
+    alpha = np.stack([o.k_inv_y(X, Y[:, l], ell[l], F[l], noise[l]) for l in range(L)])
+    Kc = np.stack([o.k_cho(X, ell[l], F[l], noise[l]) for l in range(L)])
+    ref = e.ClosedSobolWithErrorOracle(X, alpha[:, None, :], F[None, :], ell, Kc, is_T_partial=False)
+    slices = o.all_slices(M)[:-1] + [(M, M)]
+    for b in range(L):
+        gp = gpu.RcGP(X, Y[:, b])
+        gp.set_hyper(ell[b], F[b], noise[b])
+        for a in range(L):
+            got = gp.sobol_error_terms(slices) if a == b else gp.sobol_error_terms(slices, ell[a], F[a], alpha[a])
+            for s, sl in enumerate(slices):
+                want = (0.0, 0.0, 0.0, 0.0) if sl[0] == sl[1] else e.error_terms_pair(X, a, b, ref.g0, ref.g, ref.phi, ref.ups, ref.pre, Kc, sl)
+                for k in range(4):
+                    assert got[k][s] == pytest.approx(want[k], rel=1e-7, abs=1e-12), (a, b, sl, k)
+        with pytest.raises(gpu.RcgpError, match='only first-order'):
+            gp.sobol_error_terms([(1, 3)])
+        gp.close()
