@@ -12,6 +12,7 @@
  *   rcgp_get_k_cho                MOGP.K_cho value for one output, (N,N) lower                    gpr/models.py:427-439
  *   rcgp_get_k_inv_y              MOGP.K_inv_Y for one output, (N,)                               gpr/models.py:441-444
  *   rcgp_predict                  MOGP.predict -> gp.predict_y / predict_f (mean, SD)             gpr/models.py:375-384
+ *   rcgp_predict_gradient         MOGP.predict_gradient (tape.jacobian of K(X,x), triangular_solve) gpr/models.py:386-415
  *   rcgp_sobol_closed             ClosedSobol._calibrate/_V/marginalize, diagonal (l = j) term    gsa/calibrators.py:49-97
  *   rcgp_sobol_cross              the same einsum's off-diagonal (l != j) entries                 gsa/calibrators.py:79
  *   rcgp_sobol_error_terms        ClosedSobolWithError: mu_phi_mu, psi_factor, mu_psi_mu          gsa/calibrators.py:259-322
@@ -62,6 +63,11 @@ int rcgp_get_gram(rcgp_handle h, double* out /* N*N */);
 /* Posterior at n new points Xnew (n, M): mean[n] and standard deviation sd[n] (SD, not variance: gpr/models.py:384).
  * include_noise != 0 is predict_y, 0 is predict_f. */
 int rcgp_predict(rcgp_handle h, int64_t n, const double* Xnew, int include_noise, double* mean, double* sd);
+
+/* Gradient GP at n points (gpr/models.py:386-415): mean[(o*M + m)] = sum_N d k(X_N, x_o)/d x_om * alpha_N and
+ * cov[(O*M + P) * (n*M) + (o*M + p)] = sum_N V[N][O,P] V[N][o,p] with V = L^-1 d k(X, x)/dx. The caller forms the reference's
+ * var = -cov + diag term. n * M <= 4096. */
+int rcgp_predict_gradient(rcgp_handle h, int64_t n, const double* Xnew, double* mean, double* cov);
 
 /* Closed-form Sobol conditional variances for this handle's output: V[s] for each slice [slices[2s], slices[2s+1]) of
  * the input dimensions (gsa/models.py:77-90). Requires rcgp_factor. */

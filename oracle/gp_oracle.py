@@ -422,3 +422,23 @@ def gsa_calibrate(calibrator, kind: int, M: int, m: int = -1) -> Dict[str, np.nd
 def all_slices(M: int) -> List[Tuple[int, int]]:
     """The 3M slices of the three kinds followed by the full model [0,M): the 3M+1 quadratic forms per (fold, output)."""
     return gsa_slices(FIRST_ORDER, M) + gsa_slices(CLOSED, M) + gsa_slices(TOTAL, M) + [(0, M)]
+
+
+def predict_gradient(X, y, ell, var, noise, xs) -> Tuple[np.ndarray, np.ndarray]:
+    """MOGP.predict_gradient for one independent output (gpr/models.py:386-415): mean (o, M) = dK^T alpha and
+    var (o, o, M, M) = -(L^-1 dK)^T (L^-1 dK) with k(x_O, x_o)/ell_M^2 added on the M == m diagonal (:411-414), where
+    dK[N, o, M] = d k(X_N, x_o)/d x_oM (tape.jacobian at :397, analytic here). The reference ignores y_instead_of_f."""
+    N, M = X.shape
+    o_ = xs.shape[0]
+    ell = np.broadcast_to(np.asarray(ell, dtype=np.float64), (M,))
+    L = k_cho(X, ell, var, noise)
+    alpha = scipy.linalg.cho_solve((L, True), y, check_finite=False)
+    K = gram(X, ell, var, xs)                                                   # (N, o)
+    dK = -(xs[None, :, :] - X[:, None, :]) / (ell * ell) * K[:, :, None]        # (N, o, M)
+    mean = np.einsum('NoM,N->oM', dK, alpha)
+    V = scipy.linalg.solve_triangular(L, dK.reshape(N, o_ * M), lower=True, check_finite=False).reshape(N, o_, M)
+    cov = -np.einsum('NOM,Nom->OoMm', V, V)
+    kxx = gram(xs, ell, var)
+    idx = np.arange(M)
+    cov[:, :, idx, idx] += kxx[:, :, None] / (ell * ell)[None, None, :]
+    return mean, cov

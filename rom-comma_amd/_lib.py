@@ -32,6 +32,7 @@ SIGNATURES = {
     'rcgp_get_k_cho': (ctypes.c_int, [ctypes.c_void_p, _c_double_p]),
     'rcgp_get_gram': (ctypes.c_int, [ctypes.c_void_p, _c_double_p]),
     'rcgp_predict': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    'rcgp_predict_gradient': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p]),
     'rcgp_sobol_closed': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int32_p, _c_double_p]),
     'rcgp_sobol_cross': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_int, _c_int32_p, _c_double_p]),
     'rcgp_sobol_error_terms': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_int, _c_int32_p, _c_double_p,
@@ -184,6 +185,16 @@ class RcGP:
         mean, sd = np.empty(n), np.empty(n)
         self._check(self._lib.rcgp_predict(self._h, n, _dp(Xnew), int(bool(include_noise)), _dp(mean), _dp(sd)), 'rcgp_predict')
         return mean, sd
+
+    def predict_gradient(self, Xnew) -> Tuple[np.ndarray, np.ndarray]:
+        """(mean (n, M), cov (n, M, n, M)) with cov = V^T V, V = L^-1 dK/dx (the caller applies the reference's sign and diagonal term)."""
+        Xnew = _f64(Xnew)
+        if Xnew.ndim != 2 or Xnew.shape[1] != self.M:
+            raise ValueError('Xnew must be (n, M)')
+        n = Xnew.shape[0]
+        mean, cov = np.empty(n * self.M), np.empty((n * self.M, n * self.M))
+        self._check(self._lib.rcgp_predict_gradient(self._h, n, _dp(Xnew), _dp(mean), _dp(cov)), 'rcgp_predict_gradient')
+        return mean.reshape(n, self.M), cov.reshape(n, self.M, n, self.M)
 
     @staticmethod
     def _slices(slices: Sequence[Sequence[int]]) -> np.ndarray:

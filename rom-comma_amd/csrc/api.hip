@@ -23,7 +23,7 @@ RC_API int rcgp_device_count(void) {
 
 static void free_all(rcgp_handle_s* h) {
   double** bufs[] = {&h->X, &h->Z, &h->sq, &h->y, &h->w, &h->alpha, &h->A, &h->Linv, &h->S, &h->invdiag, &h->logdiag, &h->partial,
-                     &h->scal, &h->ell_d, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob};
+                     &h->scal, &h->ell_d, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob, &h->gV, &h->gC};
   for (auto b : bufs)
     if (*b) { hipFree(*b); *b = nullptr; }
   if (h->info) { hipFree(h->info); h->info = nullptr; }
@@ -344,6 +344,61 @@ RC_API int rcgp_predict(rcgp_handle h, int64_t n, const double* Xnew, int includ
       sd[o0 + i] = sqrt(v);                            // SD, not variance (gpr/models.py:384)
     }
   }
+  return 0;
+}
+
+// D[(o*M + m)][n] = d k(X_n, x_o) / d x_om = -(x_om - X_nm) / ell_m^2 * k(X_n, x_o)   (zero on the padding)
+__global__ void k_dkernel_rows(const double* __restrict__ Zs, const double* __restrict__ sqs, const double* __restrict__ Z,
+                               const double* __restrict__ sq, const double* __restrict__ ell, int64_t n_pts, int64_t N, int64_t Np, int M,
+                               double var, double* __restrict__ D) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (n >= Np) return;
+  const int64_t o = r / M;
+  const int m = (int)(r - o * M);
+  double v = 0.0;
+  if (o < n_pts && n < N) {
+    double dot = 0.0;
+    for (int mm = 0; mm < M; ++mm) dot = fma(Zs[o * M + mm], Z[n * M + mm], dot);
+    const double k = var * exp(sqs[o] + sq[n] + dot);
+    v = -(Zs[o * M + m] - Z[n * M + m]) / ell[m] * k;              // (x - X)/ell^2 = (z - Z)/ell
+  }
+  D[r * Np + n] = v;
+}
+
+RC_API int rcgp_predict_gradient(rcgp_handle h, int64_t n, const double* Xnew, double* mean, double* cov) {
+  RC_CHECK_H(h);
+  const int M = h->M;
+  if (n < 1 || !Xnew || !mean || !cov) { h->err = "rcgp_predict_gradient: bad argument"; return -2; }
+  const int64_t rows = n * M, rows_padded = ((rows + 127) / 128) * 128;
+  if (rows_padded > PRED_CAP) { h->err = "rcgp_predict_gradient: n * M exceeds 4096 (the covariance has (n M)^2 entries)"; return -6; }
+  int rc;
+  if ((rc = rcgp_factor(h))) return rc;
+  if ((rc = rc_ensure_pred(h))) return rc;
+  const int64_t Np = h->Np;
+  if (h->g_rows < rows_padded) {
+    if (h->gV) { RC_HIP(hipFree(h->gV)); h->gV = nullptr; }
+    if (h->gC) { RC_HIP(hipFree(h->gC)); h->gC = nullptr; }
+    RC_HIP(hipMalloc(&h->gV, (size_t)Np * rows_padded * sizeof(double)));
+    RC_HIP(hipMalloc(&h->gC, (size_t)rows_padded * rows_padded * sizeof(double)));
+    h->g_rows = rows_padded;
+  }
+  const int64_t np = ((n + 127) / 128) * 128;
+  if ((rc = upload_padded(h, h->Xs, Xnew, n, np, M))) return rc;
+  if ((rc = rc_launch_scale_rows(h, h->Xs, h->Zs, h->sqs, np))) return rc;
+  {
+    RcProfScope ps(h, RC_K_MISC, 0.0);
+    hipLaunchKernelGGL(k_dkernel_rows, dim3((unsigned)((Np + 255) / 256), (unsigned)rows_padded), dim3(256), 0, h->stream, h->Zs, h->sqs, h->Z,
+                       h->sq, h->ell_d, n, h->N, Np, M, h->var, h->KsT);
+    RC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_rowdot, dim3((unsigned)rows), dim3(256), 0, h->stream, h->KsT, Np, h->alpha, Np, h->pmean);
+    RC_HIP(hipGetLastError());
+  }
+  if ((rc = rc_launch_gradient_cov(h, rows_padded, h->gV, h->gC))) return rc;
+  RC_HIP(hipMemcpyAsync(mean, h->pmean, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipMemcpy2DAsync(cov, (size_t)rows * sizeof(double), h->gC, (size_t)rows_padded * sizeof(double), (size_t)rows * sizeof(double),
+                          (size_t)rows, hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
 

@@ -63,6 +63,8 @@ struct rcgp_handle_s {
   // predict scratch
   double *Xs = nullptr, *Zs = nullptr, *sqs = nullptr, *KsT = nullptr, *pmean = nullptr, *pvar = nullptr;
   int64_t pred_cap = 0;
+  double *gV = nullptr, *gC = nullptr;   // predict_gradient scratch
+  int64_t g_rows = 0;
   // sobol scratch
   double *sob = nullptr;       // prep arrays
   size_t sob_elems = 0;
@@ -124,6 +126,9 @@ int rc_launch_trtri_level(rcgp_handle_s* h, int64_t s);
 int rc_launch_grad(rcgp_handle_s* h, int* nrows);
 // predict: colsum((Linv * Ks)^2) for np test points -> h->pvar (np)
 int rc_launch_predict_var(rcgp_handle_s* h, int64_t np);
+
+// predict_gradient: V (Np x rows) = Linv * KsT^T stored, C (rows x rows) = V^T V
+int rc_launch_gradient_cov(rcgp_handle_s* h, int64_t rows_padded, double* V, double* C);
 
 // ---- potrf.hip
 int rc_potrf(rcgp_handle_s* h);                              // blocked Cholesky of A in place, w = L^-1 y, logdiag

@@ -492,3 +492,45 @@ int rc_launch_predict_var(rcgp_handle_s* h, int64_t np) {
   }
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// predict_gradient (reference gpr/models.py:386-415): V = L^-1 D^T stored (D = d k(X, x)/dx, one row per (point, dim)),
+// then C = V^T V. Two thin kernels on the same mainloop with plain store epilogues.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int WN>
+__global__ void RC_BOUNDS(WN) k_linv_times_rows(const double* __restrict__ Linv, int64_t ld, const double* __restrict__ D, int64_t ldd,
+                                                double* __restrict__ V, int64_t ldv) {
+  __shared__ double lds[GEMM_LDS];
+  const int tj = blockIdx.x;
+  const int ti = gridDim.y - 1 - blockIdx.y;
+  v4d acc[4][Geo<WN>::NI];
+  acc_zero(acc);
+  gemm_mainloop<true, true, WN>(Linv, ld, (int64_t)ti * 128, D, ldd, (int64_t)tj * 128, 0, (int64_t)(ti + 1) * 128, acc, lds);
+  acc_store<WN>(acc, V + (int64_t)ti * 128 * ldv + (int64_t)tj * 128, ldv);
+}
+
+template <int WN>
+__global__ void RC_BOUNDS(WN) k_vtv(const double* __restrict__ V, int64_t ldv, int64_t Np, double* __restrict__ C, int64_t ldc) {
+  __shared__ double lds[GEMM_LDS];
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  v4d acc[4][Geo<WN>::NI];
+  acc_zero(acc);
+  gemm_mainloop<false, false, WN>(V, ldv, (int64_t)ti * 128, V, ldv, (int64_t)tj * 128, 0, Np, acc, lds);
+  acc_store<WN>(acc, C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128, ldc);
+}
+
+int rc_launch_gradient_cov(rcgp_handle_s* h, int64_t rows_padded, double* V, double* C) {
+  const int64_t T = h->Np / 128, R = rows_padded / 128;
+  {
+    RcProfScope ps(h, RC_K_GEMM, (double)h->Np * (double)h->Np * (double)rows_padded);
+    hipLaunchKernelGGL(k_linv_times_rows<RC_WN>, dim3((unsigned)R, (unsigned)T), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->KsT, h->Np, V,
+                       rows_padded);
+    RC_HIP(hipGetLastError());
+  }
+  {
+    RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)h->Np * (double)rows_padded * (double)rows_padded);
+    hipLaunchKernelGGL(k_vtv<RC_WN>, dim3((unsigned)R, (unsigned)R), dim3(128 * RC_WN), 0, h->launch, V, rows_padded, h->Np, C, rows_padded);
+    RC_HIP(hipGetLastError());
+  }
+  return 0;
+}

@@ -340,8 +340,26 @@ class HipGP(GPR):
         sd = np.stack([r[1] for r in results], axis=1)
         return np.atleast_2d(mean), np.atleast_2d(sd)
 
-    def predict_gradient(self, x: np.ndarray, y_instead_of_f: bool = True):
-        raise NotImplementedError('predict_gradient (gpr/models.py:386-415) is not on the accelerated path yet (SURVEY.md 8f rank 3)')
+    def predict_gradient(self, x: np.ndarray, y_instead_of_f: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """The gradient GP dy/dx at the (o, M) inputs ``x`` (gpr/models.py:386-415, independent branch): mean (o, L, M) and
+        covariance (o, o, L, M, M). As in the reference: mean = dK^T alpha; cov = -(L^-1 dK)^T (L^-1 dK) with
+        k(x_O, x_o) / ell_M^2 added where the two gradient components coincide (M == m); ``y_instead_of_f`` is accepted and,
+        exactly as in the reference, has no effect. dK = d k(X, x)/dx is analytic here (tape.jacobian in the reference)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        o = x.shape[0]
+        mean = np.empty((o, self._L, self._M))
+        var = np.empty((o, o, self._L, self._M, self._M))
+        for l, record in self.implementation:
+            m_l, cov = self._select(l).predict_gradient(x)                     # (o, M), (o, M, o, M)
+            mean[:, l, :] = m_l
+            var[:, :, l, :, :] = -np.transpose(cov, (0, 2, 1, 3))              # 'LNOM, LNom -> OoLMm'
+            z = x / record['lengthscales']
+            r2 = np.sum(z * z, axis=1)[:, None] + np.sum(z * z, axis=1)[None, :] - 2.0 * z @ z.T
+            kxx = record['variance'] * np.exp(-0.5 * r2)                        # kernel(x): (o, o)
+            lam2 = np.broadcast_to(1.0 / record['lengthscales'] ** 2, (self._M,))
+            idx = np.arange(self._M)
+            var[:, :, l, idx, idx] += kxx[:, :, None] * lam2[None, None, :]    # set_diag(var, diag_part(var) + ddxxkxx)
+        return mean, var
 
     @property
     def K_cho(self) -> np.ndarray:

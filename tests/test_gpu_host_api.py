@@ -108,3 +108,33 @@ def test_run_gpr_gsa_end_to_end(gpu, tmp_path):
     assert [str(n) for n in names] == ['gpr.v.a/gsa/closed']
     collected = pd.read_csv(repo.folder / 'gpr.v.a' / 'gsa' / 'closed' / 'T.csv')
     assert list(collected.columns[:2]) == ['N', 'fold'] and collected.shape[0] == 2 * 4
+
+
+def test_predict_gradient(gpu, tmp_path):
+    """HipGP.predict_gradient (gpr/models.py:386-415): shapes (o, L, M) and (o, o, L, M, M), values against the oracle, and the
+    mean against a finite difference of predict (the gradient GP's mean is the gradient of the posterior mean)."""
+    from romcomma_amd.data.storage import Fold
+    from romcomma_amd.gpr.models import MOGP
+    repo = make_repo(tmp_path / 'repo', N=150, M=3, L=2).into_K_folds(-2, seed=1)
+    fold = Fold(repo, 0)
+    gp = MOGP('gpr.v.a', fold, False, False, False)
+    gp.kernel.data.replace(lengthscales=np.array([[0.9, 1.4, 2.2], [1.1, 0.8, 1.9]]), variance=np.array([[1.2, 0.7]]))
+    gp.likelihood.data.replace(variance=np.array([[0.02, 0.01]]))
+    gp.kernel._implementation = None
+    gp._implementation = None
+    x = fold.test_x.values[:7]
+    mean, var = gp.predict_gradient(x)
+    assert mean.shape == (7, 2, 3) and var.shape == (7, 7, 2, 3, 3)
+    for l in range(2):
+        ell, v, nse = gp.kernel.data.frames.lengthscales.np[l], gp.kernel.data.frames.variance.np[0, l], gp.likelihood.data.frames.variance.np[0, l]
+        m_ref, c_ref = o.predict_gradient(gp.X, gp.Y[:, l], ell, v, nse, x)
+        np.testing.assert_allclose(mean[:, l, :], m_ref, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(var[:, :, l, :, :], c_ref, rtol=1e-7, atol=1e-9 * np.max(np.abs(c_ref)))
+    h = 1e-5
+    for m in range(3):
+        xp, xm = x.copy(), x.copy()
+        xp[:, m] += h
+        xm[:, m] -= h
+        fd = (gp.predict(xp, False)[0] - gp.predict(xm, False)[0]) / (2 * h)
+        np.testing.assert_allclose(mean[:, :, m], fd, rtol=1e-5, atol=1e-7)
+    gp.close()

@@ -220,3 +220,19 @@ def test_sobol_error_reduced_form_matches_literal_transliteration(L, is_T_partia
         np.testing.assert_allclose(b['W'], a['W'], rtol=1e-7)
         np.testing.assert_allclose(b['T'], a['T'], rtol=1e-6, atol=1e-9)
         assert np.all(a['T'] >= 0) and np.all(np.isfinite(a['T']))
+
+
+def test_predict_gradient_oracle_is_the_gradient_of_predict():
+    X, y = o.synthetic_fold(60, 3, k=4)
+    ell, var, noise = np.array([0.9, 1.6, 2.3]), 1.2, 0.02
+    xs, _ = o.synthetic_fold(5, 3, k=14)
+    mean, cov = o.predict_gradient(X, y, ell, var, noise, xs)
+    assert mean.shape == (5, 3) and cov.shape == (5, 5, 3, 3)
+    h = 1e-6
+    for m in range(3):
+        xp, xm = xs.copy(), xs.copy()
+        xp[:, m] += h
+        xm[:, m] -= h
+        fd = (o.predict(X, y, ell, var, noise, xp, False)[0] - o.predict(X, y, ell, var, noise, xm, False)[0]) / (2 * h)
+        np.testing.assert_allclose(mean[:, m], fd, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(cov, np.transpose(cov, (1, 0, 3, 2)), rtol=1e-10, atol=1e-14)     # symmetric under (O,M) <-> (o,m)
