@@ -89,12 +89,15 @@ def main():
     ap.add_argument('--rows', dest='n', type=int, default=16384, help='training rows per fold (BASELINE configs[2]: 16384)')
     ap.add_argument('--dims', dest='m', type=int, default=10, help='input dimensions (BASELINE configs[2]: 10)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shard', choices=('folds', 'outputs'), default='folds',
+                    help="what a rank owns: fold r of an 8-fold split (default, BASELINE configs[4] style) or output column r on a shared "
+                         "design (configs[3] style)")
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group even for one rank (exercises RCCL on a 1-GPU box)')
     args = ap.parse_args()
 
     from romcomma_amd import _lib, dist
     from romcomma_amd.gpr.optimize import fit_lbfgsb
-    from romcomma_amd.user.sample import synthetic_cv_fold
+    from romcomma_amd.user.sample import synthetic_cv_fold, synthetic_outputs
 
     rank, world, local_rank = dist.env_rank_world()
     if world > 1 or args.force_dist:
@@ -105,7 +108,11 @@ def main():
 
     N, M = args.n, args.m
     K_folds = max(8, world)                          # fold r of a K-fold split of one seeded dataset: every fold trains on N rows
-    X, y = synthetic_cv_fold(N, M, k=rank, K=K_folds)
+    if args.shard == 'outputs':                      # the same design on every rank, output column r
+        X, Y = synthetic_outputs(N, M, max(8, world))
+        y = Y[:, rank]
+    else:
+        X, y = synthetic_cv_fold(N, M, k=rank, K=K_folds)
     gp = _lib.RcGP(X, y, device=local_rank)         # inputs resident in HBM from here on
     slices = all_slices(M)
     last = {}
@@ -147,8 +154,9 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'{"C2" if (N, M) == (16384, 10) else "custom"}: ARD-RBF GP fit (L-BFGS-B to convergence, reference defaults) + closed-form Sobol first/closed/'
-                                   f'total indices, N={N}, M={M}, L=1, fold r of an {K_folds}-fold split per GPU',
-                       'N': N, 'M': M, 'lbfgs_evaluations_last_step': nfev, 'parallelism': f'fold-per-gpu x{world}',
+                                   f'total indices, N={N}, M={M}, ' + (f'L=1, fold r of an {K_folds}-fold split per GPU' if args.shard == 'folds' else
+                                                          f'output r of {max(8, world)} independent outputs on one design per GPU'),
+                       'N': N, 'M': M, 'lbfgs_evaluations_last_step': nfev, 'parallelism': f'{args.shard[:-1]}-per-gpu x{world}',
                        'log_marginal': last['fit']['log_marginal']},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic(N, M),

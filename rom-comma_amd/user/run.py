@@ -90,6 +90,21 @@ def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | 
     return [full_name]
 
 
+def Y_splits_sharded(repo: Repository) -> List[Repository]:
+    """Independent outputs, one repository each (the reference's ``Repository.Y_split``, data/storage.py:226-243), dealt
+    round-robin to the ranks of the job: rank 0 writes the ``Y.l`` folders, every rank returns ITS share after the barrier.
+    Each ``Y.l`` is an ordinary single-output Repository: fold it and pass it to ``gpr`` / ``gsa`` (BASELINE configs[3]:
+    one output per GPU). Cross-output Sobol entries are not formed in this mode: they need the outputs in one process."""
+    rank, world, _ = dist.env_rank_world()
+    if rank == 0:
+        repo.Y_split()
+    if dist.is_distributed():
+        dist.barrier()
+    splits = sorted(repo.Y_splits)
+    mine = dist.shard_units(len(splits), rank, world) if world > 1 else range(len(splits))
+    return [Repository(splits[i][1]) for i in mine]
+
+
 def _names(name: str, is_covariant: Optional[bool], is_isotropic: Optional[bool]) -> List[str]:
     base = name + ('.c' if is_covariant else '.v')
     return [base + '.i', base + '.a'] if is_isotropic is None else [base + ('.i' if is_isotropic else '.a')]

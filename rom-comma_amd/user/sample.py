@@ -48,3 +48,22 @@ def synthetic_cv_fold(N: int, M: int, k: int, K: int = 8, l: int = 0, noise: flo
     keep = np.ones(N + held, dtype=bool)
     keep[start:start + held] = False
     return np.ascontiguousarray(X[keep]), np.ascontiguousarray(y[keep])
+
+
+def synthetic_outputs(N: int, M: int, L: int, k: int = 0, noise: float = 0.04) -> Tuple[np.ndarray, np.ndarray]:
+    """One design X (N, M) shared by L outputs Y (N, L) (BASELINE configs[3]: independent-output GPs on the same inputs).
+    Output l rotates the relevance hierarchy: f_l = sum_m sin(2 pi U_{(m+l) mod M}) / (m+1) + 0.5 U_l U_{l+1}."""
+    rng = np.random.Generator(np.random.PCG64(20240807 + 1000 * k))
+    U = rng.random((N, M))
+    X = scipy.stats.norm.ppf(np.clip(U, UNIFORM_MARGIN, 1 - UNIFORM_MARGIN))
+    Y = np.empty((N, L))
+    for l in range(L):
+        f = np.zeros(N)
+        for m in range(M):
+            f += np.sin(2 * np.pi * U[:, (m + l) % M]) / (m + 1)
+        if M > 1:
+            f += 0.5 * U[:, l % M] * U[:, (l + 1) % M]
+        f = (f - f.mean()) / f.std()
+        y = f + noise * np.random.Generator(np.random.PCG64(20240807 + 1000 * k + 7 * (l + 1))).standard_normal(N)
+        Y[:, l] = (y - y.mean()) / y.std()
+    return np.ascontiguousarray(X), np.ascontiguousarray(Y)

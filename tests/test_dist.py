@@ -32,6 +32,20 @@ def _worker(rank: int, world: int, port: int, tmp: str):
     assert np.array_equal(table, expected)
     assert dist.max_over_ranks(float(rank + 1)) == float(world)
     dist.barrier()
+    # output sharding through the reference's Y_split: rank 0 writes Y.0..Y.2, each rank gets its share
+    import pandas as pd
+    from romcomma_amd.data.storage import Repository
+    from romcomma_amd.user import run
+    folder = Path(tmp) / 'repo'
+    if rank == 0:
+        rng = np.random.default_rng(0)
+        columns = pd.MultiIndex.from_tuples([('X', 'X.0'), ('X', 'X.1'), ('Y', 'Y.0'), ('Y', 'Y.1'), ('Y', 'Y.2')])
+        Repository.from_df(folder, pd.DataFrame(rng.random((20, 5)), columns=columns))
+    dist.barrier()
+    mine = run.Y_splits_sharded(Repository(folder))
+    assert [r.folder.name for r in mine] == ([f'Y.{l}' for l in range(rank, 3, world)])
+    assert all(r.L == 1 and r.M == 2 and r.N == 20 for r in mine)
+    dist.barrier()
     np.save(Path(tmp) / f'ok{rank}.npy', table)
     import torch.distributed as td
     td.destroy_process_group()
