@@ -33,6 +33,8 @@ static void free_all(rcgp_handle_s* h) {
   h->event_pool.clear();
   for (auto& e : h->la_events) (void)hipEventDestroy(e);
   h->la_events.clear();
+  if (h->ev_inv) { (void)hipEventDestroy(h->ev_inv); h->ev_inv = nullptr; }
+  if (h->stream4) { (void)hipStreamDestroy(h->stream4); h->stream4 = nullptr; }
   if (h->stream3) { (void)hipStreamDestroy(h->stream3); h->stream3 = nullptr; }
   if (h->stream2) { (void)hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
   if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
@@ -75,10 +77,26 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     if (me != hipSuccess) {
       (void)hipGetLastError();
       RC_HIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+      RC_HIP(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
+    } else {
+      // the overlapped L^-1 kernels run long tiles: confine them to the upper part of the chip so that the panel chain's GEMMs
+      // (which want many CUs at once) always find free ones
+      int reserve_inv = 128;
+      if (const char* e = getenv("RCGP_RESERVE_CUS_INV")) reserve_inv = atoi(e);
+      std::vector<uint32_t> mask4((ncu + 31) / 32, 0u);
+      for (int cu = 0; cu < ncu; ++cu)
+        if (cu >= reserve_inv) mask4[cu / 32] |= (1u << (cu % 32));
+      if (reserve_inv <= 0 || reserve_inv >= ncu ||
+          hipExtStreamCreateWithCUMask(&h->stream4, (uint32_t)mask4.size(), mask4.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        RC_HIP(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
+      }
     }
+    RC_HIP(hipEventCreateWithFlags(&h->ev_inv, hipEventDisableTiming));
   }
   h->launch = h->stream;
   if (const char* e = getenv("RCGP_DIAG")) h->diag_variant = atoi(e);
+  if (const char* e = getenv("RCGP_OVERLAP_INVERSE")) h->overlap_ok = (e[0] != '0');
   if (const char* e = getenv("RCGP_LOOKAHEAD")) h->lookahead = (e[0] != '0');     // tuning knob: 0 = strictly sequential potrf
   RC_HIP(hipMalloc(&h->X, (size_t)Np * M * sizeof(double)));
   RC_HIP(hipMalloc(&h->Z, (size_t)Np * M * sizeof(double)));
@@ -176,7 +194,10 @@ static int ensure_factor(rcgp_handle_s* h, bool want_inverse) {
   if ((rc = need_hyper(h))) return rc;
   if (!h->factored) {
     if ((rc = do_gram(h))) return rc;
-    if ((rc = rc_potrf(h))) return rc;
+    h->overlap_inverse = want_inverse && h->overlap_ok;
+    rc = rc_potrf(h);
+    h->overlap_inverse = false;
+    if (rc) return rc;
   }
   if (want_inverse && !h->inverted) {
     if ((rc = rc_trtri(h))) return rc;
@@ -195,6 +216,7 @@ RC_API int rcgp_stage_gram(rcgp_handle h) {
 
 RC_API int rcgp_stage_potrf(rcgp_handle h) {
   RC_CHECK_H(h);
+  h->tt_active = false;
   return rc_potrf(h);
 }
 

@@ -30,6 +30,15 @@ struct rcgp_handle_s {
   hipStream_t stream = nullptr;      // main stream: every public call is ordered on it
   hipStream_t stream2 = nullptr;     // high-priority side stream: look-ahead panel factorisation inside rc_potrf
   hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky (normal priority)
+  hipStream_t stream4 = nullptr;     // L^-1 kernels overlapped with the chain-bound tail of the Cholesky (same CU mask as stream3)
+  hipEvent_t ev_inv = nullptr;       // last overlapped L^-1 kernel
+  bool overlap_ok = false;            // RCGP_OVERLAP_INVERSE=1 overlaps L^-1 with the Cholesky tail (measured SLOWER: long L^-1 tiles hold the
+                                      // CUs the panel chain needs: 109 vs 85 ms per evaluation at C2), so it is off
+  bool overlap_inverse = false;      // set by the caller of rc_potrf when L^-1 will be needed
+  int64_t tt_put_rows = 0;           // incremental L^-1 schedule: diagonal blocks copied so far
+  std::vector<int> tt_next_pair;     // per level: first pair not yet completed
+  std::vector<int> tt_T_rows;        // per level: C-part row tiles of that pair whose T phase is already issued
+  bool tt_active = false;
   hipStream_t launch = nullptr;      // the stream kernels are currently launched on (stream or stream2)
   std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing)
   bool lookahead = true;
@@ -120,8 +129,10 @@ int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0);
 // panel trsm: P (m x 128) <- P * invL^T ; rhs (m) -= P_new * wj (128)
 int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double* invL, int64_t m, double* rhs, const double* wj);
-// trtri level: for each pair p at block size s. T = B * Ainv (lower-tri Ainv); X21 = -Cinv * T
-int rc_launch_trtri_level(rcgp_handle_s* h, int64_t s);
+// L^-1 by recursive doubling, level s: T = B * Ainv (lower-tri Ainv) for C-part row tiles [ti0, ti0+nti) of pairs
+// [pair0, pair0+npairs); X21 = -Cinv * T for whole pairs
+int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti0, int nti);
+int rc_launch_trtri_X(rcgp_handle_s* h, int64_t s, int pair0, int npairs);
 // K^-1 tiles fused with the LML-gradient reduction; partial sums -> h->partial ; returns number of partial rows via *nrows
 int rc_launch_grad(rcgp_handle_s* h, int* nrows);
 // predict: colsum((Linv * Ks)^2) for np test points -> h->pvar (np)
@@ -135,7 +146,9 @@ int rc_potrf(rcgp_handle_s* h);                              // blocked Cholesky
 int rc_launch_diag(rcgp_handle_s* h, int64_t j);             // factor + invert diagonal block j (row/col offset), w_j
 
 // ---- solve.hip
-int rc_trtri(rcgp_handle_s* h);                              // Linv = L^-1
+int rc_trtri_begin(rcgp_handle_s* h);                        // allocate Linv/S, reset the incremental schedule
+int rc_trtri_advance(rcgp_handle_s* h, int64_t done_rows);   // launch (on h->launch) every L^-1 kernel whose inputs are rows < done_rows of L
+int rc_trtri(rcgp_handle_s* h);                              // Linv = L^-1 (whatever the incremental schedule has not issued yet)
 int rc_alpha(rcgp_handle_s* h);                              // alpha = Linv^T w
 int rc_lml_value(rcgp_handle_s* h, double* lml);             // from logdiag and w
 int rc_grad_finish(rcgp_handle_s* h, int nrows, double* grad);

@@ -272,10 +272,10 @@ int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double*
 // ---------------------------------------------------------------------------------------------------------------------
 template <int WN>
 __global__ void RC_BOUNDS(WN) k_trtri_T(const double* __restrict__ Lm, const double* __restrict__ W, double* __restrict__ S, int64_t ld,
-                                        int64_t Np, int64_t s) {
+                                        int64_t Np, int64_t s, int pair0, int ti0) {
   __shared__ double lds[GEMM_LDS];
-  const int ti = blockIdx.x, tj = blockIdx.y;                 // tj slow: the longest k-ranges (small tj) are dispatched first
-  const int64_t colA = 2 * s * (int64_t)blockIdx.z, rowC = colA + s;
+  const int ti = ti0 + blockIdx.x, tj = blockIdx.y;           // tj slow: the longest k-ranges (small tj) are dispatched first
+  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z), rowC = colA + s;
   if (rowC + (int64_t)ti * 128 >= Np) return;
   v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
@@ -286,10 +286,10 @@ __global__ void RC_BOUNDS(WN) k_trtri_T(const double* __restrict__ Lm, const dou
 }
 
 template <int WN>
-__global__ void RC_BOUNDS(WN) k_trtri_X(double* __restrict__ W, const double* __restrict__ S, int64_t ld, int64_t Np, int64_t s) {
+__global__ void RC_BOUNDS(WN) k_trtri_X(double* __restrict__ W, const double* __restrict__ S, int64_t ld, int64_t Np, int64_t s, int pair0) {
   __shared__ double lds[GEMM_LDS];
   const int tj = blockIdx.x, ti = (int)gridDim.y - 1 - (int)blockIdx.y;   // ti slow and reversed: longest k-ranges first
-  const int64_t colA = 2 * s * (int64_t)blockIdx.z, rowC = colA + s;
+  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z), rowC = colA + s;
   if (rowC + (int64_t)ti * 128 >= Np) return;
   v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
@@ -299,27 +299,24 @@ __global__ void RC_BOUNDS(WN) k_trtri_X(double* __restrict__ W, const double* __
   acc_store<WN>(acc, W + (rowC + (int64_t)ti * 128) * ld + colA + (int64_t)tj * 128, ld);
 }
 
-int rc_launch_trtri_level(rcgp_handle_s* h, int64_t s) {
-  const int64_t Np = h->Np;
-  const int64_t pairs = (Np + 2 * s - 1) / (2 * s);
+// T phase of `npairs` pairs starting at pair0 on level s, C-part row tiles [ti0, ti0 + nti); X phase of whole pairs.
+int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti0, int nti) {
+  if (npairs <= 0 || nti <= 0) return 0;
   const int64_t st = s / 128;
-  // skip the last pair when it has no C block
-  int64_t npairs = 0;
-  for (int64_t p = 0; p < pairs; ++p)
-    if (2 * s * p + s < Np) npairs = p + 1;
-  if (npairs == 0) return 0;
-  {
-    RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)s * (double)s * (double)s);
-    hipLaunchKernelGGL(k_trtri_T<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->launch, h->A, h->Linv,
-                       h->S, Np, Np, s);
-    RC_HIP(hipGetLastError());
-  }
-  {
-    RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)s * (double)s * (double)s);
-    hipLaunchKernelGGL(k_trtri_X<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->S,
-                       Np, Np, s);
-    RC_HIP(hipGetLastError());
-  }
+  RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)nti * 128.0 * (double)s * (double)s);
+  hipLaunchKernelGGL(k_trtri_T<RC_WN>, dim3((unsigned)nti, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->launch, h->A, h->Linv, h->S,
+                     h->Np, h->Np, s, pair0, ti0);
+  RC_HIP(hipGetLastError());
+  return 0;
+}
+
+int rc_launch_trtri_X(rcgp_handle_s* h, int64_t s, int pair0, int npairs) {
+  if (npairs <= 0) return 0;
+  const int64_t st = s / 128;
+  RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)s * (double)s * (double)s);
+  hipLaunchKernelGGL(k_trtri_X<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->S, h->Np,
+                     h->Np, s, pair0);
+  RC_HIP(hipGetLastError());
   return 0;
 }
 

@@ -487,6 +487,9 @@ int rc_potrf(rcgp_handle_s* h) {
   RC_HIP(hipMemsetAsync(h->info, 0, sizeof(int), h->stream));
   const int64_t npanels = (Np + NB - 1) / NB;
   const bool la = h->lookahead && npanels > 2;
+  const bool inv = la && h->overlap_inverse;                      // feed L^-1 kernels into the idle CUs of the chain-bound tail
+  h->tt_active = false;                                            // any earlier incremental schedule is void: L is being rebuilt
+  if (inv && (rc = rc_trtri_begin(h))) return rc;
   while (la && (int64_t)h->la_events.size() < 3 * npanels + 1) {
     hipEvent_t e;
     RC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -510,6 +513,13 @@ int rc_potrf(rcgp_handle_s* h) {
       h->launch = h->stream;
       if (rc) return rc;
       RC_HIP(hipEventRecord(ev_panel, h->stream2));
+      if (inv) {                                                   // rows < Jend2 of L are final once panel J+1 is done
+        RC_HIP(hipStreamWaitEvent(h->stream4, ev_panel, 0));
+        h->launch = h->stream4;
+        rc = rc_trtri_advance(h, Jend2);
+        h->launch = h->stream;
+        if (rc) return rc;
+      }
       // (bulk stream) the rest of the trailing matrix, concurrently with the panel
       RC_HIP(hipStreamWaitEvent(h->stream3, ev_next, 0));
       if (Np - Jend2 > 0) {
@@ -527,6 +537,10 @@ int rc_potrf(rcgp_handle_s* h) {
       }
       if ((rc = panel_factor(h, Jend, Jend2))) return rc;
     }
+  }
+  if (inv) {
+    RC_HIP(hipEventRecord(h->ev_inv, h->stream4));
+    RC_HIP(hipStreamWaitEvent(h->stream, h->ev_inv, 0));
   }
   h->factored = true;
   h->inverted = false;
