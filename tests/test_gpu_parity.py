@@ -70,7 +70,7 @@ def test_literal_multi_output_fixture(gpu):
 # oracle on seeded inputs, incl. ragged sizes around the 128 tile edge and the extremes of M
 # --------------------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize('N,M', [(1, 1), (2, 3), (127, 2), (128, 5), (129, 4), (383, 6), (640, 3), (1500, 10), (200, 64), (513, 33)])
+@pytest.mark.parametrize('N,M', [(1, 1), (2, 3), (127, 2), (128, 5), (129, 4), (383, 6), (640, 3), (1500, 10), (1600, 4), (200, 64), (513, 33)])
 def test_against_oracle(gpu, N, M):
     X, y = o.synthetic_fold(N, M, k=N % 7)
     rng = np.random.default_rng(N + M)
@@ -278,3 +278,49 @@ def test_sobol_error_terms(gpu, L):
         with pytest.raises(gpu.RcgpError, match='only first-order'):
             gp.sobol_error_terms([(1, 3)])
         gp.close()
+
+
+@pytest.mark.parametrize('env', [{'RCGP_DIAG': '1'}, {'RCGP_LOOKAHEAD': '0'}, {'RCGP_RESERVE_CUS': '0'}, {'RCGP_OVERLAP_INVERSE': '1'}])
+def test_tuning_knobs_do_not_change_results(gpu, env, monkeypatch):
+    """Every run-time variant (register-sweep diagonal kernel, sequential Cholesky, no reserved CUs, overlapped inverse) is the
+    same arithmetic up to rounding: LML, gradient and alpha against the oracle at a size with a ragged last outer panel."""
+    for key, value in env.items():
+        monkeypatch.setenv(key, value)
+    N, M = 1700, 4
+    X, y = o.synthetic_fold(N, M, k=3)
+    ell, var, noise = np.array([0.8, 1.3, 2.0, 2.9]), 1.1, 0.02
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(ell, var, noise)
+    lml_ref, grad_ref = o.lml_and_grad(X, y, ell, var, noise)
+    lml, grad = gp.lml_grad()
+    assert lml == pytest.approx(lml_ref, rel=1e-10)
+    np.testing.assert_allclose(grad, grad_ref, rtol=1e-7, atol=1e-9 * np.max(np.abs(grad_ref)))
+    assert relmax(gp.k_inv_y(), o.k_inv_y(X, y, ell, var, noise)) < 1e-9
+    gp.close()
+
+
+def test_sobol_error_terms_many_dimensions(gpu):
+    """M = 20 (BASELINE configs[4]): the matvec kernel's LDS footprint grows with M; values against the reduced-form oracle."""
+    from oracle import sobol_error_oracle as e
+    N, M = 150, 20
+    X, y = o.synthetic_fold(N, M, k=6)
+    ell = np.random.default_rng(3).uniform(2.0, 6.0, M)
+    F, noise = 1.2, 0.03
+    alpha = o.k_inv_y(X, y, ell, F, noise)
+    Kc = o.k_cho(X, ell, F, noise)[None]
+    ref = e.ClosedSobolWithErrorOracle(X, alpha[None, None, :], np.array([[F]]), ell[None, :], Kc, is_T_partial=False)
+    slices = [(0, 1), (7, 8), (0, 5), (0, M), (12, M), (M - 1, M)]
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(ell, F, noise)
+    got = gp.sobol_error_terms(slices)
+    for s, sl in enumerate(slices):
+        want = e.error_terms_pair(X, 0, 0, ref.g0, ref.g, ref.phi, ref.ups, ref.pre, Kc, sl)
+        for k in range(4):
+            assert got[k][s] == pytest.approx(want[k], rel=1e-6, abs=1e-12 * abs(want[0]) + 1e-15), (sl, k)
+    gp.close()
+    X30, y30 = o.synthetic_fold(64, 30)
+    gp = gpu.RcGP(X30, y30)
+    gp.set_hyper(np.full(30, 3.0), 1.0, 0.05)
+    with pytest.raises(gpu.RcgpError, match='at most 29'):
+        gp.sobol_error_terms([(0, 1)])
+    gp.close()
