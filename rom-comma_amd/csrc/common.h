@@ -42,6 +42,7 @@ struct rcgp_handle_s {
   hipStream_t launch = nullptr;      // the stream kernels are currently launched on (stream or stream2)
   std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing)
   bool lookahead = true;
+  bool diag_attr_set = false;
   int diag_variant = 2;              // 2 = MFMA 16-blocked kernel (k_diag2), 1 = register column sweep (k_diag)
   int64_t N = 0, Np = 0;       // rows, rows padded to a multiple of RC_TILE
   int M = 0;

@@ -444,10 +444,9 @@ int rc_launch_diag(rcgp_handle_s* h, int64_t j) {
     hipLaunchKernelGGL(k_diag, dim3(1), dim3(512), 0, h->launch, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
   } else {
     const size_t lds = (size_t)(128 * LS + 8 * 16 * XS + 256 + 32) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!h->diag_attr_set) {                                   // per handle = per device (the attribute is device state)
       RC_HIP(hipFuncSetAttribute((const void*)k_diag2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
+      h->diag_attr_set = true;
     }
     hipLaunchKernelGGL(k_diag2, dim3(1), dim3(512), lds, h->launch, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
   }
