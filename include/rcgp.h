@@ -95,11 +95,12 @@ int rcgp_stage_trtri(rcgp_handle h);     /* L^-1 and alpha; requires rcgp_stage_
 int rcgp_sync(rcgp_handle h);
 
 /* ---- profiling: HIP events around every kernel launch on the handle's stream ---- */
-enum { RCGP_K_GRAM = 0, RCGP_K_GEMM = 1, RCGP_K_DIAG = 2, RCGP_K_SOBOL = 3, RCGP_K_MISC = 4, RCGP_K_COUNT = 5 };
+enum { RCGP_K_GRAM = 0, RCGP_K_GEMM = 1, RCGP_K_DIAG = 2, RCGP_K_SOBOL = 3, RCGP_K_MISC = 4, RCGP_K_GRAD = 5, RCGP_K_COUNT = 6 };
 int rcgp_set_profiling(rcgp_handle h, int on);
 int rcgp_profile_reset(rcgp_handle h);
 /* For kernel class cls: number of launches, summed launch duration (ms) and summed ALGORITHMIC work since the last
- * reset: bytes for GRAM, flops for GEMM and DIAG, exp evaluations for SOBOL. */
+ * reset: bytes for GRAM, flops for GEMM, DIAG and GRAD (k_grad alone: N^3/3 per launch), exp evaluations for SOBOL.
+ * Kernels of the look-ahead Cholesky overlap on several streams, so the summed GEMM durations exceed the wall time. */
 int rcgp_profile_get(rcgp_handle h, int cls, int64_t* launches, double* total_ms, double* work);
 
 #ifdef __cplusplus

@@ -46,8 +46,8 @@ SIGNATURES = {
     'rcgp_profile_get': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int64_p, _c_double_p, _c_double_p]),
 }
 
-K_GRAM, K_GEMM, K_DIAG, K_SOBOL, K_MISC = range(5)
-KERNEL_CLASS_NAMES = ('gram', 'gemm', 'diag', 'sobol', 'misc')
+K_GRAM, K_GEMM, K_DIAG, K_SOBOL, K_MISC, K_GRAD = range(6)
+KERNEL_CLASS_NAMES = ('gram', 'gemm', 'diag', 'sobol', 'misc', 'grad')
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -35,6 +35,7 @@ static void free_all(rcgp_handle_s* h) {
   h->la_events.clear();
   if (h->ev_inv) { (void)hipEventDestroy(h->ev_inv); h->ev_inv = nullptr; }
   if (h->stream4) { (void)hipStreamDestroy(h->stream4); h->stream4 = nullptr; }
+  if (h->stream5) { (void)hipStreamDestroy(h->stream5); h->stream5 = nullptr; }
   if (h->stream3) { (void)hipStreamDestroy(h->stream3); h->stream3 = nullptr; }
   if (h->stream2) { (void)hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
   if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
@@ -60,6 +61,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     int lo = 0, hi = 0;
     RC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // hi is the numerically lowest = highest priority
     RC_HIP(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
+    RC_HIP(hipStreamCreateWithPriority(&h->stream5, hipStreamNonBlocking, hi));
   }
   {
     // The bulk-update stream may use every CU except the first RCGP_RESERVE_CUS, which stay free for the panel chain.
@@ -98,6 +100,23 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   if (const char* e = getenv("RCGP_DIAG")) h->diag_variant = atoi(e);
   if (const char* e = getenv("RCGP_OVERLAP_INVERSE")) h->overlap_ok = (e[0] != '0');
   if (const char* e = getenv("RCGP_LOOKAHEAD")) h->lookahead = (e[0] != '0');     // tuning knob: 0 = strictly sequential potrf
+  if (const char* e = getenv("RCGP_FINE")) h->fine_chain = (e[0] != '0');         // 0 = one stream per panel chain (D, T, G in order)
+  if (const char* e = getenv("RCGP_EXT")) {
+    const int x = atoi(e);
+    if (x >= 1 && x <= 16) h->chain_ext = x;
+  }
+  if (const char* e = getenv("RCGP_INV_EVERY")) {
+    const int x = atoi(e);
+    if (x >= 1) h->inv_every = x;
+  }
+  if (const char* e = getenv("RCGP_DEPTH")) {
+    const int x = atoi(e);
+    if (x >= 1 && x <= 64) h->chain_depth = x;
+  }
+  if (const char* e = getenv("RCGP_NB")) {
+    const int64_t nb = atoll(e);
+    if (nb >= 128 && nb <= 4096 && nb % 128 == 0) h->nb_outer = nb;
+  }
   RC_HIP(hipMalloc(&h->X, (size_t)Np * M * sizeof(double)));
   RC_HIP(hipMalloc(&h->Z, (size_t)Np * M * sizeof(double)));
   RC_HIP(hipMalloc(&h->sq, (size_t)Np * sizeof(double)));

@@ -16,11 +16,12 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // Profiled kernel classes (rcgp_profile_get). Order is part of the ABI (include/rcgp.h).
 enum RcKernelClass {
   RC_K_GRAM = 0,       // Gram build
-  RC_K_GEMM = 1,       // fp64 MFMA GEMM family (trailing update, trsm, trtri, K^-1/gradient, predict)
+  RC_K_GEMM = 1,       // fp64 MFMA GEMM family (trailing update, trsm, trtri, predict), except k_grad
   RC_K_DIAG = 2,       // 128x128 diagonal-block potrf + inverse
   RC_K_SOBOL = 3,      // Sobol pair kernel
   RC_K_MISC = 4,       // reductions, gemv, prep
-  RC_K_COUNT = 5
+  RC_K_GRAD = 5,       // k_grad: fused K^-1 + LML-gradient reduction (the largest single kernel of an evaluation)
+  RC_K_COUNT = 6
 };
 
 struct RcProfEvent { hipEvent_t start, stop; int cls; };
@@ -31,6 +32,7 @@ struct rcgp_handle_s {
   hipStream_t stream2 = nullptr;     // high-priority side stream: look-ahead panel factorisation inside rc_potrf
   hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky (normal priority)
   hipStream_t stream4 = nullptr;     // L^-1 kernels overlapped with the chain-bound tail of the Cholesky (same CU mask as stream3)
+  hipStream_t stream5 = nullptr;     // column work of the fine-grained panel chain (T2/G kernels, potrf.hip)
   hipEvent_t ev_inv = nullptr;       // last overlapped L^-1 kernel
   bool overlap_ok = false;            // RCGP_OVERLAP_INVERSE=1 overlaps L^-1 with the Cholesky tail (measured SLOWER: long L^-1 tiles hold the
                                       // CUs the panel chain needs: 109 vs 85 ms per evaluation at C2), so it is off
@@ -40,8 +42,14 @@ struct rcgp_handle_s {
   std::vector<int> tt_T_rows;        // per level: C-part row tiles of that pair whose T phase is already issued
   bool tt_active = false;
   hipStream_t launch = nullptr;      // the stream kernels are currently launched on (stream or stream2)
-  std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing)
+  std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing), handed out in order by rc_next_event
+  size_t la_cursor = 0;
   bool lookahead = true;
+  bool fine_chain = true;            // split every chain step into a critical single-workgroup part and column work (RCGP_FINE)
+  int64_t nb_outer = RC_NB_OUTER;    // outer panel width (RCGP_NB)
+  int inv_every = 8;                 // with overlap_inverse: L^-1 kernels are fed every inv_every panels (RCGP_INV_EVERY)
+  int chain_depth = 4;               // column panels updated by their own kernels ahead of the bulk trailing update (RCGP_DEPTH >= 1)
+  int chain_ext = 2;                 // 128-blocks past its own panel that a chain step keeps up to date (RCGP_EXT >= 1)
   bool diag_attr_set = false;
   int diag_variant = 2;              // 2 = MFMA 16-blocked kernel (k_diag2), 1 = register column sweep (k_diag)
   int64_t N = 0, Np = 0;       // rows, rows padded to a multiple of RC_TILE
@@ -82,9 +90,9 @@ struct rcgp_handle_s {
   bool profiling = false;
   std::vector<RcProfEvent> prof_events;
   std::vector<hipEvent_t> event_pool;     // recycled events (no create/destroy on the launch path after warm-up)
-  double prof_ms[RC_K_COUNT] = {0, 0, 0, 0, 0};
-  long prof_count[RC_K_COUNT] = {0, 0, 0, 0, 0};
-  double prof_work[RC_K_COUNT] = {0, 0, 0, 0, 0};   // algorithmic flops (GEMM) or bytes (Gram) or pair-terms (Sobol)
+  double prof_ms[RC_K_COUNT] = {0, 0, 0, 0, 0, 0};
+  long prof_count[RC_K_COUNT] = {0, 0, 0, 0, 0, 0};
+  double prof_work[RC_K_COUNT] = {0, 0, 0, 0, 0, 0};   // algorithmic flops (GEMM) or bytes (Gram) or pair-terms (Sobol)
   std::string err;
 };
 
@@ -130,6 +138,9 @@ int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0);
 // panel trsm: P (m x 128) <- P * invL^T ; rhs (m) -= P_new * wj (128)
 int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double* invL, int64_t m, double* rhs, const double* wj);
+// critical step of the fine-grained chain, one workgroup: T (128 x 128, below the diagonal block) <- T * invL^T,
+// rhs (128) -= T_new * wj, then D (the next diagonal block) -= T_new * T_new^T
+int rc_launch_prep_next(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
 // L^-1 by recursive doubling, level s: T = B * Ainv (lower-tri Ainv) for C-part row tiles [ti0, ti0+nti) of pairs
 // [pair0, pair0+npairs); X21 = -Cinv * T for whole pairs
 int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti0, int nti);

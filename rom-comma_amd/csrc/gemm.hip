@@ -217,17 +217,14 @@ int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double
 // Panel triangular solve as a GEMM with the explicit inverse of the diagonal block: P <- P * invL^T (in place), and the
 // fused forward substitution of the right-hand side: rhs[rows] -= P_new * wj.
 // ---------------------------------------------------------------------------------------------------------------------
+// One 128-row tile of the panel solve: Pt (128 x 128) <- Pt * invL^T in place, rhs_t (128) -= Pt_new * wj.
 template <int WN>
-__global__ void RC_BOUNDS(WN) k_trsm_panel(double* __restrict__ P, int64_t ldp, const double* __restrict__ invL, double* __restrict__ rhs,
-                                           const double* __restrict__ wj) {
-  __shared__ double lds[GEMM_LDS];
-  __shared__ double rowsum[WN][128];
-  const int ti = blockIdx.x;
+__device__ __forceinline__ void trsm_tile(double* Pt, int64_t ldp, const double* __restrict__ invL, double* rhs_t,
+                                          const double* __restrict__ wj, double* lds, double (*rowsum)[128]) {
   v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
-  gemm_mainloop<true, true, WN>(P, ldp, (int64_t)ti * 128, invL, 128, 0, 0, 128, acc, lds);
+  gemm_mainloop<true, true, WN>(Pt, ldp, 0, invL, 128, 0, 0, 128, acc, lds);
   RC_LANE_VARS(WN)
-  double* Pt = P + (int64_t)ti * 128 * ldp;
   double wv[NI_];
 #pragma unroll
   for (int ni = 0; ni < NI_; ++ni) wv[ni] = wj[wc_ + 16 * ni + fr_];
@@ -254,8 +251,42 @@ __global__ void RC_BOUNDS(WN) k_trsm_panel(double* __restrict__ P, int64_t ldp, 
     double s = 0.0;
 #pragma unroll
     for (int c = 0; c < WN; ++c) s += rowsum[c][threadIdx.x];
-    rhs[(int64_t)ti * 128 + threadIdx.x] -= s;
+    rhs_t[threadIdx.x] -= s;
   }
+}
+
+template <int WN>
+__global__ void RC_BOUNDS(WN) k_trsm_panel(double* __restrict__ P, int64_t ldp, const double* __restrict__ invL, double* __restrict__ rhs,
+                                           const double* __restrict__ wj) {
+  __shared__ double lds[GEMM_LDS];
+  __shared__ double rowsum[WN][128];
+  const int ti = blockIdx.x;
+  trsm_tile<WN>(P + (int64_t)ti * 128 * ldp, ldp, invL, rhs + (int64_t)ti * 128, wj, lds, rowsum);
+}
+
+// Critical step of the fine-grained panel chain (potrf.hip), ONE workgroup: the tile T right below the diagonal block that has
+// just been factored becomes L_{j+1,j} = T * inv(L_jj)^T (rhs rows updated as in the panel solve), and the next diagonal
+// block receives its last update D -= L_{j+1,j} L_{j+1,j}^T, so the next diagonal kernel can start while the rest of the
+// column is still being solved on another stream. The second product reads the tile this workgroup has just written:
+// __syncthreads() orders global memory at workgroup scope, and one workgroup runs on one CU (one L1).
+template <int WN>
+__global__ void __launch_bounds__(128 * WN) k_prep_next(double* T, double* D, int64_t ld, const double* __restrict__ invL, double* rhs,
+                                          const double* __restrict__ wj) {
+  __shared__ double lds[GEMM_LDS];
+  __shared__ double rowsum[WN][128];
+  trsm_tile<WN>(T, ld, invL, rhs, wj, lds, rowsum);
+  __syncthreads();
+  v4d acc[4][Geo<WN>::NI];
+  acc_load<WN>(acc, D, ld);
+  gemm_mainloop<true, true, WN, true>(T, ld, 0, T, ld, 0, 0, 128, acc, lds);
+  acc_store<WN>(acc, D, ld);
+}
+
+int rc_launch_prep_next(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
+  RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0 + 128.0 * 129.0 * 128.0);
+  hipLaunchKernelGGL(k_prep_next<RC_WN>, dim3(1), dim3(128 * RC_WN), 0, h->launch, T, D, ld, invL, rhs, wj);
+  RC_HIP(hipGetLastError());
+  return 0;
 }
 
 int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double* invL, int64_t m, double* rhs, const double* wj) {
@@ -421,7 +452,7 @@ int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
   int rc = rc_ensure_partial(h, (size_t)nb * (h->M + 2));
   if (rc) return rc;
   const double np = (double)h->Np;
-  RcProfScope ps(h, RC_K_GEMM, np * np * np / 3.0);
+  RcProfScope ps(h, RC_K_GRAD, np * np * np / 3.0);
   if (h->M <= 32)
     hipLaunchKernelGGL((k_grad<33, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
                        h->sq, h->alpha, h->var, h->partial);

@@ -288,6 +288,16 @@ __device__ __forceinline__ double xval(const double* S, const double* Xd, int i,
   return ((i >> 4) == (j >> 4)) ? Xd[((i >> 4) * 16 + (i & 15)) * XS + (j & 15)] : S[j * LS + i];
 }
 
+#ifdef RC_DIAG_TIMING
+__device__ long long g_diag_t[32];
+#define RC_T(i) do { if (threadIdx.x == 0) g_diag_t[i] = wall_clock64(); } while (0)
+extern "C" __attribute__((visibility("default"))) int rcgp_debug_diag_times(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_t), sizeof(long long) * 32);
+}
+#else
+#define RC_T(i)
+#endif
+
 __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
                                                double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
   extern __shared__ double S[];                    // [128][LS], then Xd[8][16][XS], rsd[128], rv[128]
@@ -298,16 +308,19 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   double* At = A + j0 * ld + j0;
+  RC_T(0);
   for (int e = t; e < 128 * 128; e += 512) {
     const int i = e >> 7, j = e & 127;
     S[i * LS + j] = (j <= i) ? At[(int64_t)i * ld + j] : 0.0;
   }
   if (t < 128) rv[t] = rhs[j0 + t];
   __syncthreads();
+  RC_T(1);
 
   // ------------------------------------------------------------------ blocked Cholesky
   if (wave == 0) pivot_block_16(S, Xd, rsd, pcol, info, j0, 0, lane);
   __syncthreads();
+  RC_T(2);
 #pragma unroll 1
   for (int c = 0; c < 8; ++c) {
     // (b) panel: L_rc = S_rc * Xcc^T, r = c+1..7, one tile per wave round-robin
@@ -324,6 +337,7 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
       for (int q = 0; q < 4; ++q) S[(16 * rb + fq + 4 * q) * LS + 16 * c + fr] = acc[q];
     }
     __syncthreads();
+    RC_T(3 + 2 * c);
     if (c == 7) break;
     // (c) trailing update of the lower tiles (rb, cb), c < cb <= rb. Tile (c+1,c+1) goes to wave 0, which then factors the
     //     next pivot block while the other waves finish the remaining tiles.
@@ -351,6 +365,7 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
       }
     }
     __syncthreads();
+    RC_T(4 + 2 * c);
   }
 
   // L back to global (lower + diagonal, zeros above), log-diagonal
@@ -359,6 +374,7 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
     At[(int64_t)i * ld + j] = (j <= i) ? S[i * LS + j] : 0.0;
   }
   if (t < 128) logdiag[j0 + t] = -log(rsd[t]);
+  RC_T(19);
 
 #ifndef RC_DIAG2_NO_INVERSE
   // ------------------------------------------------------------------ inverse by recursive doubling
@@ -419,6 +435,7 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
       for (int q = 0; q < 4; ++q) S[(16 * cb + fr) * LS + 16 * rb + fq + 4 * q] = tacc[nt][q];
     }
     __syncthreads();
+    RC_T(20 + (sb == 1 ? 0 : sb == 2 ? 1 : 2));
   }
 
 #endif
@@ -435,6 +452,7 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
     s += __shfl_xor(s, 2);
     if (h4 == 0) rhs[j0 + i] = s;
   }
+  RC_T(23);
 }
 
 int rc_launch_diag(rcgp_handle_s* h, int64_t j) {
@@ -474,12 +492,127 @@ static int panel_factor(rcgp_handle_s* h, int64_t J, int64_t Jend) {
   return 0;
 }
 
+static int next_event(rcgp_handle_s* h, hipEvent_t* out) {
+  if (h->la_cursor == h->la_events.size()) {
+    hipEvent_t e;
+    RC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->la_events.push_back(e);
+  }
+  *out = h->la_events[h->la_cursor++];
+  return 0;
+}
+
+// Fine-grained blocked Cholesky. The critical path of the factorisation is the sequence of 128x128 diagonal blocks;
+// everything else only has to be ready one step (or one panel) later. Per 128-column block j, on four streams:
+//   C  (h->stream2, high priority): D(j) = diagonal kernel; P(j) = k_prep_next: tile (j+1, j) solved, block (j+1, j+1) updated.
+//                                   D(j+1) follows P(j) in stream order, so a chain step costs D + P, not D + T + G.
+//   B  (h->stream5, high priority): T2(j) = panel solve of the rows from block j+2 on (after D(j));
+//                                   G(j)  = K=128 update of block columns [j+1, cend) for the rows from block j+2 on (after P(j));
+//                                   P(j+1) waits for G(j), which has had the whole of D(j+1) to finish.
+//   U1 (h->stream, main)          : when panel p = [pend-NB, pend) is complete, the K=NB update of the NB columns from u0 on
+//   U2 (h->stream3, CU-masked)    : ... and of everything beyond them (the bulk of the flops), concurrently with the next chain.
+// cend = pend + EXT: the G updates reach EXT columns past their own panel, so the first blocks of the NEXT panel are already
+// up to date when the chain arrives there (u0 = pend + EXT) and the chain never waits at a panel boundary: U1(p) only has to
+// finish before G of the first block of panel p+1.
+static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
+  const int64_t Np = h->Np, NB = h->nb_outer, EXT = 128 * (int64_t)h->chain_ext;
+  hipStream_t C = h->stream2, B = h->stream5, U1 = h->stream, U2 = h->stream3;
+  int rc;
+  hipEvent_t e0;
+  if ((rc = next_event(h, &e0))) return rc;
+  RC_HIP(hipEventRecord(e0, h->stream));
+  RC_HIP(hipStreamWaitEvent(C, e0, 0));
+  RC_HIP(hipStreamWaitEvent(B, e0, 0));
+  hipEvent_t eG_prev = nullptr, eU1_prev = nullptr, eU2_prev = nullptr;
+  for (int64_t j = 0; j < Np; j += 128) {
+    h->launch = C;
+    if ((rc = rc_launch_diag(h, j))) return rc;
+    const int64_t below = Np - (j + 128);
+    if (below <= 0) break;
+    const int64_t pend = (j / NB + 1) * NB;                      // end of the panel block j belongs to
+    const int64_t cend = (pend + EXT < Np) ? pend + EXT : Np;    // G(j) covers the block columns [j + 128, cend)
+    const bool first_of_panel = (j > 0 && j % NB == 0);
+    double* P = h->A + (j + 128) * Np + j;                       // rows below the diagonal block, 128 columns
+    const double* inv = h->invdiag + (j / 128) * 128 * 128;
+    hipEvent_t eD, eP, eG;
+    if ((rc = next_event(h, &eD)) || (rc = next_event(h, &eP)) || (rc = next_event(h, &eG))) return rc;
+    RC_HIP(hipEventRecord(eD, C));
+    RC_HIP(hipStreamWaitEvent(B, eD, 0));
+    if (eG_prev) RC_HIP(hipStreamWaitEvent(C, eG_prev, 0));
+    if (first_of_panel && eU1_prev && h->chain_ext < 2) RC_HIP(hipStreamWaitEvent(C, eU1_prev, 0));   // P touches column j + 128 >= u0
+    if ((rc = rc_launch_prep_next(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j))) return rc;
+    RC_HIP(hipEventRecord(eP, C));
+    h->launch = B;
+    if (below > 128) {
+      if ((rc = rc_launch_trsm_panel(h, P + 128 * Np, Np, inv, below - 128, h->w + j + 256, h->w + j))) return rc;
+      if (first_of_panel && eU1_prev) RC_HIP(hipStreamWaitEvent(B, eU1_prev, 0));
+      RC_HIP(hipStreamWaitEvent(B, eP, 0));
+      if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + (j + 128), Np, P + 128 * Np, Np, P, Np, below - 128, cend - (j + 128), 128,
+                                      j + 256, j + 128)))
+        return rc;
+    }
+    RC_HIP(hipEventRecord(eG, B));
+    eG_prev = eG;
+    if (j + 128 == pend) {                                        // panel [pend - NB, pend) is final once B has finished this step
+      // Outer (K = NB) updates with the finished panel, by target column panel: the next `depth` (shifted) panels one kernel
+      // each, in column order on the main stream -- the first one is what the chain is waiting for -- and everything beyond
+      // them in one bulk kernel on the CU-masked stream. A column panel leaves the bulk kernel's domain one panel before the
+      // chain reaches it with depth 1, `depth` panels before with a deeper window: the chain may run that far ahead of the bulk.
+      eU1_prev = nullptr;
+      const int depth = h->chain_depth;
+      const double* Lp0 = h->A + (pend - NB);                     // column offset of the finished panel
+      hipEvent_t eR_new = nullptr;
+      for (int q = 0; q <= depth; ++q) {
+        const int64_t u0 = pend + EXT + (int64_t)q * NB;
+        if (u0 >= Np) break;
+        const int64_t u1 = (u0 + NB < Np) ? u0 + NB : Np;
+        if (q < depth) {                                          // window piece
+          if (q == 0) RC_HIP(hipStreamWaitEvent(U1, eG, 0));
+          if (q == depth - 1 && eU2_prev) RC_HIP(hipStreamWaitEvent(U1, eU2_prev, 0));   // this panel was in the previous bulk kernel
+          h->launch = U1;
+          if ((rc = rc_launch_gemm_nt_sub(h, h->A + u0 * Np + u0, Np, Lp0 + u0 * Np, Np, Lp0 + u0 * Np, Np, Np - u0, u1 - u0, NB, u0, u0)))
+            return rc;
+          if (q == 0) {
+            hipEvent_t eU1;
+            if ((rc = next_event(h, &eU1))) return rc;
+            RC_HIP(hipEventRecord(eU1, U1));
+            eU1_prev = eU1;
+          }
+        } else {                                                  // bulk: everything from u0 on
+          if ((rc = next_event(h, &eR_new))) return rc;
+          RC_HIP(hipStreamWaitEvent(U2, eG, 0));
+          h->launch = U2;
+          if ((rc = rc_launch_syrk_lower(h, h->A + u0 * Np + u0, Np, Lp0 + u0 * Np, Np, Np - u0, NB))) return rc;
+          RC_HIP(hipEventRecord(eR_new, U2));
+        }
+      }
+      eU2_prev = eR_new;
+      if (overlap_inverse && (pend / NB) % h->inv_every == 0) {   // rows < pend of L are final: feed the L^-1 kernels that only need those
+        RC_HIP(hipStreamWaitEvent(h->stream4, eG, 0));
+        h->launch = h->stream4;
+        if ((rc = rc_trtri_advance(h, pend))) return rc;
+      }
+    }
+  }
+  h->launch = h->stream;
+  hipEvent_t eC, eB;
+  if ((rc = next_event(h, &eC)) || (rc = next_event(h, &eB))) return rc;
+  RC_HIP(hipEventRecord(eC, C));
+  RC_HIP(hipEventRecord(eB, B));
+  RC_HIP(hipStreamWaitEvent(h->stream, eC, 0));
+  RC_HIP(hipStreamWaitEvent(h->stream, eB, 0));
+  if (eU2_prev) RC_HIP(hipStreamWaitEvent(h->stream, eU2_prev, 0));
+  if (overlap_inverse) {
+    RC_HIP(hipEventRecord(h->ev_inv, h->stream4));
+    RC_HIP(hipStreamWaitEvent(h->stream, h->ev_inv, 0));
+  }
+  return 0;
+}
+
 // Right-looking blocked Cholesky with one-panel look-ahead: as soon as the trailing update has finished the NEXT panel's
-// columns, that panel is factored on the high-priority side stream while the main stream updates the rest of the trailing
-// matrix. The panel chain (latency-bound diagonal blocks, K=128 GEMMs) leaves the critical path while the bulk update is
-// longer than it.
+// columns, that panel is factored on the side streams while the bulk stream updates the rest of the trailing matrix.
 int rc_potrf(rcgp_handle_s* h) {
-  const int64_t Np = h->Np, NB = RC_NB_OUTER;
+  const int64_t Np = h->Np, NB = h->nb_outer;
   int rc;
   h->launch = h->stream;
   RC_HIP(hipMemcpyAsync(h->w, h->y, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -488,24 +621,28 @@ int rc_potrf(rcgp_handle_s* h) {
   const bool la = h->lookahead && npanels > 2;
   const bool inv = la && h->overlap_inverse;                      // feed L^-1 kernels into the idle CUs of the chain-bound tail
   h->tt_active = false;                                            // any earlier incremental schedule is void: L is being rebuilt
+  h->la_cursor = 0;
+  const bool fine = la && h->fine_chain;
   if (inv && (rc = rc_trtri_begin(h))) return rc;
-  while (la && (int64_t)h->la_events.size() < 3 * npanels + 1) {
-    hipEvent_t e;
-    RC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    h->la_events.push_back(e);
+  if (fine) {
+    if ((rc = potrf_fine(h, inv))) return rc;
+    h->factored = true;
+    h->inverted = false;
+    return 0;
   }
   if ((rc = panel_factor(h, 0, NB < Np ? NB : Np))) return rc;
-  int64_t step = 0;
-  for (int64_t J = 0; J + NB < Np; J += NB, ++step) {
+  for (int64_t J = 0; J + NB < Np; J += NB) {
     const int64_t Jend = J + NB;
     const int64_t Jend2 = (Jend + NB < Np) ? Jend + NB : Np;
     const double* P = h->A + Jend * Np + J;                      // panel J below its own rows: (Np - Jend) x NB
     // (main) the next panel's columns first
     if ((rc = rc_launch_gemm_nt_sub(h, h->A + Jend * Np + Jend, Np, P, Np, P, Np, Np - Jend, Jend2 - Jend, NB, Jend, Jend))) return rc;
     if (la) {
-      hipEvent_t ev_next = h->la_events[3 * step], ev_panel = h->la_events[3 * step + 1], ev_rest = h->la_events[3 * step + 2];
+      hipEvent_t ev_next, ev_panel, ev_rest;
+      if ((rc = next_event(h, &ev_next)) || (rc = next_event(h, &ev_rest))) return rc;
       RC_HIP(hipEventRecord(ev_next, h->stream));
-      // (side, high priority) factor panel J+1
+      // (side streams) factor panel J+1
+      if ((rc = next_event(h, &ev_panel))) return rc;
       RC_HIP(hipStreamWaitEvent(h->stream2, ev_next, 0));
       h->launch = h->stream2;
       rc = panel_factor(h, Jend, Jend2);

@@ -280,10 +280,14 @@ def test_sobol_error_terms(gpu, L):
         gp.close()
 
 
-@pytest.mark.parametrize('env', [{'RCGP_DIAG': '1'}, {'RCGP_LOOKAHEAD': '0'}, {'RCGP_RESERVE_CUS': '0'}, {'RCGP_OVERLAP_INVERSE': '1'}])
+@pytest.mark.parametrize('env', [{'RCGP_DIAG': '1'}, {'RCGP_LOOKAHEAD': '0'}, {'RCGP_RESERVE_CUS': '0'}, {'RCGP_OVERLAP_INVERSE': '1'},
+                                 {'RCGP_FINE': '0'}, {'RCGP_FINE': '0', 'RCGP_OVERLAP_INVERSE': '1'},
+                                 {'RCGP_NB': '256', 'RCGP_EXT': '1', 'RCGP_DEPTH': '1'}, {'RCGP_NB': '128', 'RCGP_EXT': '3', 'RCGP_DEPTH': '8'},
+                                 {'RCGP_NB': '384', 'RCGP_DEPTH': '2'}, {'RCGP_OVERLAP_INVERSE': '1', 'RCGP_INV_EVERY': '1', 'RCGP_NB': '256'}])
 def test_tuning_knobs_do_not_change_results(gpu, env, monkeypatch):
-    """Every run-time variant (register-sweep diagonal kernel, sequential Cholesky, no reserved CUs, overlapped inverse) is the
-    same arithmetic up to rounding: LML, gradient and alpha against the oracle at a size with a ragged last outer panel."""
+    """Every run-time variant (register-sweep diagonal kernel, sequential Cholesky, no reserved CUs, overlapped inverse, coarse
+    panel chain, other panel widths / window depths / chain extensions of the fine-grained Cholesky) is the same arithmetic up to
+    rounding: LML, gradient and alpha against the oracle at a size with a ragged last outer panel."""
     for key, value in env.items():
         monkeypatch.setenv(key, value)
     N, M = 1700, 4
@@ -296,6 +300,25 @@ def test_tuning_knobs_do_not_change_results(gpu, env, monkeypatch):
     assert lml == pytest.approx(lml_ref, rel=1e-10)
     np.testing.assert_allclose(grad, grad_ref, rtol=1e-7, atol=1e-9 * np.max(np.abs(grad_ref)))
     assert relmax(gp.k_inv_y(), o.k_inv_y(X, y, ell, var, noise)) < 1e-9
+    gp.close()
+
+
+@pytest.mark.parametrize('env', [{}, {'RCGP_NB': '256', 'RCGP_DEPTH': '3'}, {'RCGP_EXT': '1', 'RCGP_DEPTH': '12'}])
+def test_fine_grained_cholesky_factor_many_panels(gpu, env, monkeypatch):
+    """The four-stream Cholesky (diagonal chain, column work, window pieces, bulk update) over 7+ outer panels with a ragged last
+    one: the factor itself, entry by entry, against LAPACK on the oracle's Gram matrix, and w = L^-1 y through the LML."""
+    for key, value in env.items():
+        monkeypatch.setenv(key, value)
+    N, M = 3400, 3
+    X, y = o.synthetic_fold(N, M, k=11)
+    ell, var, noise = np.array([0.7, 1.5, 2.4]), 0.9, 0.01
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(ell, var, noise)
+    Lc = gp.k_cho()
+    Lref = o.k_cho(X, ell, var, noise)
+    assert relmax(Lc, Lref) < 1e-11
+    assert np.all(np.triu(Lc, 1) == 0.0)
+    assert gp.lml() == pytest.approx(o.lml(X, y, ell, var, noise), rel=1e-11)
     gp.close()
 
 

@@ -80,7 +80,7 @@ def timings(N, M, reps=3, grad=True, sobol=True):
         gp.stage_potrf()
     gp.sync()
     names = L.KERNEL_CLASS_NAMES
-    for c in range(5):
+    for c in range(len(names)):
         n, ms, work = gp.profile_get(c)
         if n:
             print(f'  [{names[c]:5s}] launches {n:6d} total {ms:9.3f} ms  work/time {work / (ms * 1e-3) / 1e12:8.3f} T(unit)/s')
