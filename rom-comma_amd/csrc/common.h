@@ -47,6 +47,7 @@ struct rcgp_handle_s {
   bool lookahead = true;
   bool fine_chain = true;            // split every chain step into a critical single-workgroup part and column work (RCGP_FINE)
   int64_t nb_outer = RC_NB_OUTER;    // outer panel width (RCGP_NB)
+  int staged_io = 3;                 // bit 0: C tiles are read through LDS, bit 1: written through LDS (RCGP_STAGED)
   int inv_every = 8;                 // with overlap_inverse: L^-1 kernels are fed every inv_every panels (RCGP_INV_EVERY)
   int chain_depth = 4;               // column panels updated by their own kernels ahead of the bulk trailing update (RCGP_DEPTH >= 1)
   int chain_ext = 2;                 // 128-blocks past its own panel that a chain step keeps up to date (RCGP_EXT >= 1)

@@ -14,7 +14,11 @@
 #include "common.h"
 #include "rc_math.h"
 
-#define LDK 18          // row stride (doubles) of a KC=true LDS slab: [128][18]
+#ifndef LDK
+#define LDK 17          // row stride (doubles) of a KC=true LDS slab: [128][17]. ODD: hipcc fuses the fragment reads into
+                        // ds_read2_b64, which is banked over 32 dwords in groups of 16 consecutive lanes (16 rows of one k):
+                        // stride 18 was two-way conflicted there (SQ_LDS_BANK_CONFLICT 5 cycles per LDS instruction), 17 is not
+#endif
 #define LDR 144         // row stride (doubles) of a KC=false LDS slab: [16][144]
 #define SLAB 2304       // doubles per operand slab (both layouts)
 #define GEMM_LDS (4 * SLAB)
@@ -58,7 +62,11 @@ __device__ __forceinline__ void slab_store(double* lds, const RegsN<WN>& rg) {
   if (KC) {
     const int kk = (t & 7) * 2, r = t >> 3;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) *reinterpret_cast<double2*>(lds + (r + (NT / 8) * p) * LDK + kk) = rg.v[p];
+    for (int p = 0; p < NP; ++p) {
+      double* d = lds + (r + (NT / 8) * p) * LDK + kk;           // rows are only 8-byte aligned with an odd stride
+      d[0] = rg.v[p].x;
+      d[1] = rg.v[p].y;
+    }
   } else {
     const int r = (t & 63) * 2, k = t >> 6;
 #pragma unroll
@@ -161,28 +169,79 @@ __device__ __forceinline__ void acc_store(const v4d (&acc)[4][Geo<WN>::NI], doub
   RC_FOR_ACC(mi, ni, r, row, col) { Ct[(int64_t)row * ldc + col] = acc[mi][ni][r]; }
 }
 
+// The same through LDS, 64 tile rows at a time ([64][LDW] doubles = the whole operand ring, free outside the main loop): the MFMA
+// C/D layout gives a lane four DIFFERENT rows of one column, i.e. 64 eight-byte accesses per lane for a tile; staged, every
+// lane moves 16 sixteen-byte pieces of whole rows instead. LDW = 144: the two rows a half-wave touches per ds access fall on
+// disjoint bank halves.
+#define LDW 144
+template <int WN>
+__device__ __forceinline__ void acc_load_staged(v4d (&acc)[4][Geo<WN>::NI], const double* Ct, int64_t ldc, double* lds) {
+  RC_LANE_VARS(WN)
+  const int row0 = threadIdx.x >> 6, c2 = (threadIdx.x & 63) * 2;
+  constexpr int RSTEP = 2 * WN;                              // rows covered by one pass of the workgroup
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+    for (int p = 0; p < 64 / RSTEP; ++p) {
+      const int row = row0 + RSTEP * p;
+      *reinterpret_cast<double2*>(lds + row * LDW + c2) = *reinterpret_cast<const double2*>(Ct + (int64_t)(64 * hh + row) * ldc + c2);
+    }
+    __syncthreads();
+    if (wr_ == 64 * hh) {
+      RC_FOR_ACC(mi, ni, r, row, col) { acc[mi][ni][r] = lds[(row - wr_) * LDW + col]; }
+    }
+    __syncthreads();
+  }
+}
+
+template <int WN>
+__device__ __forceinline__ void acc_store_staged(const v4d (&acc)[4][Geo<WN>::NI], double* Ct, int64_t ldc, double* lds) {
+  RC_LANE_VARS(WN)
+  const int row0 = threadIdx.x >> 6, c2 = (threadIdx.x & 63) * 2;
+  constexpr int RSTEP = 2 * WN;
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    if (wr_ == 64 * hh) {
+      RC_FOR_ACC(mi, ni, r, row, col) { lds[(row - wr_) * LDW + col] = acc[mi][ni][r]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 64 / RSTEP; ++p) {
+      const int row = row0 + RSTEP * p;
+      *reinterpret_cast<double2*>(Ct + (int64_t)(64 * hh + row) * ldc + c2) = *reinterpret_cast<const double2*>(lds + row * LDW + c2);
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // C[i][j] -= sum_k P[i][k] P[j][k] on the lower tiles of an n x n matrix (trailing update of the blocked Cholesky).
 // The accumulators start from the C tile (its loads overlap the first operand slabs) and the product is subtracted in
 // the MFMA chain, so the epilogue is stores only.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int WN>
+template <int WN, int STAGED>
 __global__ void RC_BOUNDS(WN) k_syrk_lower(double* __restrict__ C, int64_t ldc, const double* __restrict__ P, int64_t ldp, int kk) {
   __shared__ double lds[GEMM_LDS];
   int ti, tj;
   tri_decode(blockIdx.x, ti, tj);
   v4d acc[4][Geo<WN>::NI];
   double* Ct = C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128;
-  acc_load<WN>(acc, Ct, ldc);
+  if (STAGED & 1) acc_load_staged<WN>(acc, Ct, ldc, lds); else acc_load<WN>(acc, Ct, ldc);
   gemm_mainloop<true, true, WN, true>(P, ldp, (int64_t)ti * 128, P, ldp, (int64_t)tj * 128, 0, kk, acc, lds);
-  acc_store<WN>(acc, Ct, ldc);
+  if (STAGED & 2) acc_store_staged<WN>(acc, Ct, ldc, lds); else acc_store<WN>(acc, Ct, ldc);
 }
 
 int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk) {
   const int64_t T = n / 128;
   if (T <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, (double)n * (double)(n + 128) * (double)kk);   // 2*kk flops per lower-tile element
-  hipLaunchKernelGGL(k_syrk_lower<RC_WN>, dim3((unsigned)(T * (T + 1) / 2)), dim3(128 * RC_WN), 0, h->launch, C, ldc, P, ldp, (int)kk);
+  const dim3 grid((unsigned)(T * (T + 1) / 2)), block(128 * RC_WN);
+  switch (h->staged_io) {
+    case 0: hipLaunchKernelGGL((k_syrk_lower<RC_WN, 0>), grid, block, 0, h->launch, C, ldc, P, ldp, (int)kk); break;
+    case 1: hipLaunchKernelGGL((k_syrk_lower<RC_WN, 1>), grid, block, 0, h->launch, C, ldc, P, ldp, (int)kk); break;
+    case 2: hipLaunchKernelGGL((k_syrk_lower<RC_WN, 2>), grid, block, 0, h->launch, C, ldc, P, ldp, (int)kk); break;
+    default: hipLaunchKernelGGL((k_syrk_lower<RC_WN, 3>), grid, block, 0, h->launch, C, ldc, P, ldp, (int)kk); break;
+  }
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -190,7 +249,7 @@ int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double*
 // ---------------------------------------------------------------------------------------------------------------------
 // C (m x n) -= A (m x kk) * B (n x kk)^T, skipping tiles strictly above the global diagonal.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int WN>
+template <int WN, int STAGED>
 __global__ void RC_BOUNDS(WN) k_gemm_nt_sub(double* __restrict__ C, int64_t ldc, const double* __restrict__ A, int64_t lda,
                                             const double* __restrict__ B, int64_t ldb, int kk, int64_t row0, int64_t col0) {
   __shared__ double lds[GEMM_LDS];
@@ -198,17 +257,22 @@ __global__ void RC_BOUNDS(WN) k_gemm_nt_sub(double* __restrict__ C, int64_t ldc,
   if (col0 + (int64_t)tj * 128 > row0 + (int64_t)ti * 128) return;
   v4d acc[4][Geo<WN>::NI];
   double* Ct = C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128;
-  acc_load<WN>(acc, Ct, ldc);
+  if (STAGED & 1) acc_load_staged<WN>(acc, Ct, ldc, lds); else acc_load<WN>(acc, Ct, ldc);
   gemm_mainloop<true, true, WN, true>(A, lda, (int64_t)ti * 128, B, ldb, (int64_t)tj * 128, 0, kk, acc, lds);
-  acc_store<WN>(acc, Ct, ldc);
+  if (STAGED & 2) acc_store_staged<WN>(acc, Ct, ldc, lds); else acc_store<WN>(acc, Ct, ldc);
 }
 
 int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0) {
   if (m <= 0 || n <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)m * (double)n * (double)kk);
-  hipLaunchKernelGGL(k_gemm_nt_sub<RC_WN>, dim3((unsigned)(n / 128), (unsigned)(m / 128)), dim3(128 * RC_WN), 0, h->launch, C, ldc, A, lda,
-                     B, ldb, (int)kk, row0, col0);
+  const dim3 grid((unsigned)(n / 128), (unsigned)(m / 128)), block(128 * RC_WN);
+  switch (h->staged_io) {
+    case 0: hipLaunchKernelGGL((k_gemm_nt_sub<RC_WN, 0>), grid, block, 0, h->launch, C, ldc, A, lda, B, ldb, (int)kk, row0, col0); break;
+    case 1: hipLaunchKernelGGL((k_gemm_nt_sub<RC_WN, 1>), grid, block, 0, h->launch, C, ldc, A, lda, B, ldb, (int)kk, row0, col0); break;
+    case 2: hipLaunchKernelGGL((k_gemm_nt_sub<RC_WN, 2>), grid, block, 0, h->launch, C, ldc, A, lda, B, ldb, (int)kk, row0, col0); break;
+    default: hipLaunchKernelGGL((k_gemm_nt_sub<RC_WN, 3>), grid, block, 0, h->launch, C, ldc, A, lda, B, ldb, (int)kk, row0, col0); break;
+  }
   RC_HIP(hipGetLastError());
   return 0;
 }

@@ -11,7 +11,7 @@ import glob
 import json
 import sys
 
-GEMM = ('k_syrk_lower', 'k_gemm_nt_sub', 'k_trsm_panel', 'k_trtri_T', 'k_trtri_X', 'k_grad', 'k_predict_var')
+GEMM = ('k_syrk_lower', 'k_gemm_nt_sub', 'k_trsm_panel', 'k_prep_next', 'k_trtri_T', 'k_trtri_X', 'k_grad', 'k_predict_var')
 
 
 def rows(folder, name):
@@ -28,6 +28,8 @@ def main(fetch_dir, write_dir, busy_dir, out):
         seen = collections.defaultdict(set)
         for r in rows(folder, 'counter_collection'):
             k = short(r['Kernel_Name'])
+            if r['Counter_Name'] == 'GRBM_GUI_ACTIVE' and folder != busy_dir:
+                continue                                         # the clock reference is the one of the MFMA-busy pass
             per[k][r['Counter_Name']] += float(r['Counter_Value'])
             seen[k].add(r['Dispatch_Id'])
         for k, ids in seen.items():

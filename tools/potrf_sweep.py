@@ -13,13 +13,7 @@ from romcomma_amd import _lib                                      # noqa: E402
 from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 KNOBS = [
-    {'RCGP_DEPTH': '4'},
-    {'RCGP_DEPTH': '2', 'RCGP_LL_CORNER': '4096', 'RCGP_RESERVE_CUS_INV': '24'},
-    {'RCGP_DEPTH': '3', 'RCGP_LL_CORNER': '4096', 'RCGP_RESERVE_CUS_INV': '24'},
-    {'RCGP_DEPTH': '4', 'RCGP_LL_CORNER': '4096', 'RCGP_RESERVE_CUS_INV': '24'},
-    {'RCGP_DEPTH': '4', 'RCGP_LL_CORNER': '2048', 'RCGP_RESERVE_CUS_INV': '24'},
-    {'RCGP_DEPTH': '4', 'RCGP_LL_CORNER': '6144', 'RCGP_RESERVE_CUS_INV': '24'},
-    {'RCGP_DEPTH': '6', 'RCGP_LL_CORNER': '4096', 'RCGP_RESERVE_CUS_INV': '24'},
+    {'RCGP_STAGED': '3'},
 ]
 
 
