@@ -13,7 +13,14 @@ from romcomma_amd import _lib                                      # noqa: E402
 from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 KNOBS = [
-    {'RCGP_STAGED': '3'},
+    {'RCGP_FINE': '0'},
+    {},
+    {'RCGP_DEPTH': '1'},
+    {'RCGP_DEPTH': '8'},
+    {'RCGP_NB': '256'},
+    {'RCGP_NB': '1024', 'RCGP_DEPTH': '2'},
+    {'RCGP_EXT': '1'},
+    {'RCGP_RESERVE_CUS': '8'},
 ]
 
 
