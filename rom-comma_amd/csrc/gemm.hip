@@ -1,8 +1,8 @@
 // fp64 MFMA GEMM family for gfx950 (v_mfma_f64_16x16x4_f64).
 //
-// One workgroup = 256 threads = 4 waves (2x2), one 128x128 output tile; each wave owns 64x64 = 4x4 MFMA tiles
-// (16 accumulators x 4 doubles).  Operands are staged global -> registers -> LDS in k-slabs of 16 with a two-stage LDS
-// ring (one barrier per slab); fragments are read back with conflict-free ds_read_b64.
+// One workgroup = 512 threads = 8 waves (2x4), one 128x128 output tile; each wave owns 64x32 = 4x2 MFMA tiles
+// (8 accumulators x 4 doubles; geometry: struct Geo below).  Operands are staged global -> registers -> LDS in k-slabs of 16
+// with a two-stage LDS ring (one barrier per slab); fragment reads are bank-conflict free (row strides LDK / LDR below).
 //
 // Two operand storage kinds are supported, selected at compile time:
 //   KC = true  : element (r, k) of the operand lives at src[r*ld + k]   (k contiguous: "A[i][k]" or "B^T[j][k]")

@@ -167,6 +167,27 @@ def test_not_positive_definite_is_reported(gpu):
     gp.close()
 
 
+def test_not_positive_definite_inside_the_multi_stream_cholesky(gpu):
+    """The same failure deep inside the four-stream factorisation (4 outer panels): the duplicate of row 700 sits at row 1500, so
+    the first non-positive pivot is found by a diagonal kernel of the third panel, long after the chain, the column work and the
+    outer updates have been queued. The run must drain, report a leading minor in that neighbourhood and leave the handle usable."""
+    N = 2000
+    X, y = o.synthetic_fold(N, 3, k=8)
+    X[1500] = X[700]
+    gp = gpu.RcGP(X, y)
+    ell = np.array([0.05, 0.06, 0.07])                   # short lengthscales: K is close to the identity apart from the duplicate
+    gp.set_hyper(ell, 1.0, 0.0)
+    with pytest.raises(gpu.NotPositiveDefiniteError) as info:
+        gp.lml_grad()
+    assert 1501 <= info.value.k <= N
+    gp.set_hyper(ell, 1.0, 1e-2)
+    lml, grad = gp.lml_grad()
+    lml_ref, grad_ref = o.lml_and_grad(X, y, ell, 1.0, 1e-2)
+    assert lml == pytest.approx(lml_ref, rel=1e-9)
+    np.testing.assert_allclose(grad, grad_ref, rtol=1e-6, atol=1e-8 * np.max(np.abs(grad_ref)))
+    gp.close()
+
+
 def test_argument_errors(gpu):
     X, y = o.synthetic_fold(64, 2)
     gp = gpu.RcGP(X, y)
