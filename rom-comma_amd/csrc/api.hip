@@ -105,7 +105,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     const int x = atoi(e);
     if (x >= 1 && x <= 16) h->chain_ext = x;
   }
-  if (const char* e = getenv("RCGP_STAGED")) h->staged_io = atoi(e) & 3;
+  if (const char* e = getenv("RCGP_EXTEV")) h->ext_events = (e[0] != '0');
   if (const char* e = getenv("RCGP_INV_EVERY")) {
     const int x = atoi(e);
     if (x >= 1) h->inv_every = x;

@@ -2,6 +2,7 @@
 // The public C ABI is include/rcgp.h; nothing here is exported.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -42,12 +43,13 @@ struct rcgp_handle_s {
   std::vector<int> tt_T_rows;        // per level: C-part row tiles of that pair whose T phase is already issued
   bool tt_active = false;
   hipStream_t launch = nullptr;      // the stream kernels are currently launched on (stream or stream2)
+  hipEvent_t launch_stop = nullptr;  // if set: the next RC_LAUNCH attaches this event to its dispatch (no separate marker packet)
+  bool ext_events = true;            // chain events ride on the kernel dispatches instead of hipEventRecord (RCGP_EXTEV)
   std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing), handed out in order by rc_next_event
   size_t la_cursor = 0;
   bool lookahead = true;
   bool fine_chain = true;            // split every chain step into a critical single-workgroup part and column work (RCGP_FINE)
   int64_t nb_outer = RC_NB_OUTER;    // outer panel width (RCGP_NB)
-  int staged_io = 3;                 // bit 0: C tiles are read through LDS, bit 1: written through LDS (RCGP_STAGED)
   int inv_every = 8;                 // with overlap_inverse: L^-1 kernels are fed every inv_every panels (RCGP_INV_EVERY)
   int chain_depth = 4;               // column panels updated by their own kernels ahead of the bulk trailing update (RCGP_DEPTH >= 1)
   int chain_ext = 2;                 // 128-blocks past its own panel that a chain step keeps up to date (RCGP_EXT >= 1)
@@ -104,6 +106,18 @@ struct rcgp_handle_s {
       h->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
       return -100 - (int)e_;                                                               \
     }                                                                                      \
+  } while (0)
+
+// Kernel launch on h->launch. A pending h->launch_stop is recorded by the dispatch itself (hipExtLaunchKernelGGL): on the panel
+// chain that saves one barrier packet per event between two dependent kernels of a queue.
+#define RC_LAUNCH(kernel, grid, block, lds, ...)                                                              \
+  do {                                                                                                       \
+    if (h->launch_stop) {                                                                                    \
+      hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), h->launch, nullptr, h->launch_stop, 0u, __VA_ARGS__); \
+      h->launch_stop = nullptr;                                                                              \
+    } else {                                                                                                 \
+      hipLaunchKernelGGL(kernel, grid, block, lds, h->launch, __VA_ARGS__);                                  \
+    }                                                                                                        \
   } while (0)
 
 // RAII-less profiling bracket: records events around one kernel launch when profiling is on.

@@ -459,14 +459,14 @@ int rc_launch_diag(rcgp_handle_s* h, int64_t j) {
   RcProfScope ps(h, RC_K_DIAG, 128.0 * 128.0 * 128.0 / 3.0);
   double* inv = h->invdiag + (j / 128) * 128 * 128;
   if (h->diag_variant == 1) {
-    hipLaunchKernelGGL(k_diag, dim3(1), dim3(512), 0, h->launch, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
+    RC_LAUNCH(k_diag, dim3(1), dim3(512), 0, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
   } else {
     const size_t lds = (size_t)(128 * LS + 8 * 16 * XS + 256 + 32) * sizeof(double);
     if (!h->diag_attr_set) {                                   // per handle = per device (the attribute is device state)
       RC_HIP(hipFuncSetAttribute((const void*)k_diag2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       h->diag_attr_set = true;
     }
-    hipLaunchKernelGGL(k_diag2, dim3(1), dim3(512), lds, h->launch, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
+    RC_LAUNCH(k_diag2, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
   }
   RC_HIP(hipGetLastError());
   return 0;
@@ -488,6 +488,15 @@ static int panel_factor(rcgp_handle_s* h, int64_t J, int64_t Jend) {
       double* C = h->A + (j + 128) * Np + (j + 128);
       if ((rc = rc_launch_gemm_nt_sub(h, C, Np, P, Np, P, Np, below, rest, 128, j + 128, j + 128))) return rc;
     }
+  }
+  return 0;
+}
+
+// An event handed to the next launch (h->launch_stop) that no dispatch has taken (a launcher that returned early): record it.
+static int flush_stop(rcgp_handle_s* h) {
+  if (h->launch_stop) {
+    RC_HIP(hipEventRecord(h->launch_stop, h->launch));
+    h->launch_stop = nullptr;
   }
   return 0;
 }
@@ -524,34 +533,42 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
   RC_HIP(hipStreamWaitEvent(C, e0, 0));
   RC_HIP(hipStreamWaitEvent(B, e0, 0));
   hipEvent_t eG_prev = nullptr, eU1_prev = nullptr, eU2_prev = nullptr;
+  const bool ext = h->ext_events && !h->profiling;              // (the profiling bracket records its own events around a launch)
   for (int64_t j = 0; j < Np; j += 128) {
-    h->launch = C;
-    if ((rc = rc_launch_diag(h, j))) return rc;
     const int64_t below = Np - (j + 128);
+    hipEvent_t eD = nullptr, eP, eG;
+    if (below > 0 && (rc = next_event(h, &eD))) return rc;
+    h->launch = C;
+    if (ext) h->launch_stop = eD;
+    if ((rc = rc_launch_diag(h, j)) || (rc = flush_stop(h))) return rc;
     if (below <= 0) break;
     const int64_t pend = (j / NB + 1) * NB;                      // end of the panel block j belongs to
     const int64_t cend = (pend + EXT < Np) ? pend + EXT : Np;    // G(j) covers the block columns [j + 128, cend)
     const bool first_of_panel = (j > 0 && j % NB == 0);
     double* P = h->A + (j + 128) * Np + j;                       // rows below the diagonal block, 128 columns
     const double* inv = h->invdiag + (j / 128) * 128 * 128;
-    hipEvent_t eD, eP, eG;
-    if ((rc = next_event(h, &eD)) || (rc = next_event(h, &eP)) || (rc = next_event(h, &eG))) return rc;
-    RC_HIP(hipEventRecord(eD, C));
+    if ((rc = next_event(h, &eP)) || (rc = next_event(h, &eG))) return rc;
+    if (!ext) RC_HIP(hipEventRecord(eD, C));
     RC_HIP(hipStreamWaitEvent(B, eD, 0));
     if (eG_prev) RC_HIP(hipStreamWaitEvent(C, eG_prev, 0));
     if (first_of_panel && eU1_prev && h->chain_ext < 2) RC_HIP(hipStreamWaitEvent(C, eU1_prev, 0));   // P touches column j + 128 >= u0
-    if ((rc = rc_launch_prep_next(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j))) return rc;
-    RC_HIP(hipEventRecord(eP, C));
+    if (ext) h->launch_stop = eP;
+    if ((rc = rc_launch_prep_next(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j)) || (rc = flush_stop(h))) return rc;
+    if (!ext) RC_HIP(hipEventRecord(eP, C));
     h->launch = B;
     if (below > 128) {
       if ((rc = rc_launch_trsm_panel(h, P + 128 * Np, Np, inv, below - 128, h->w + j + 256, h->w + j))) return rc;
       if (first_of_panel && eU1_prev) RC_HIP(hipStreamWaitEvent(B, eU1_prev, 0));
       RC_HIP(hipStreamWaitEvent(B, eP, 0));
+      if (ext) h->launch_stop = eG;
       if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + (j + 128), Np, P + 128 * Np, Np, P, Np, below - 128, cend - (j + 128), 128,
-                                      j + 256, j + 128)))
+                                      j + 256, j + 128)) ||
+          (rc = flush_stop(h)))
         return rc;
+      if (!ext) RC_HIP(hipEventRecord(eG, B));
+    } else {
+      RC_HIP(hipEventRecord(eG, B));
     }
-    RC_HIP(hipEventRecord(eG, B));
     eG_prev = eG;
     if (j + 128 == pend) {                                        // panel [pend - NB, pend) is final once B has finished this step
       // Outer (K = NB) updates with the finished panel, by target column panel: the next `depth` (shifted) panels one kernel
@@ -570,20 +587,25 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
           if (q == 0) RC_HIP(hipStreamWaitEvent(U1, eG, 0));
           if (q == depth - 1 && eU2_prev) RC_HIP(hipStreamWaitEvent(U1, eU2_prev, 0));   // this panel was in the previous bulk kernel
           h->launch = U1;
-          if ((rc = rc_launch_gemm_nt_sub(h, h->A + u0 * Np + u0, Np, Lp0 + u0 * Np, Np, Lp0 + u0 * Np, Np, Np - u0, u1 - u0, NB, u0, u0)))
+          hipEvent_t eU1 = nullptr;
+          if (q == 0) {
+            if ((rc = next_event(h, &eU1))) return rc;
+            if (ext) h->launch_stop = eU1;
+          }
+          if ((rc = rc_launch_gemm_nt_sub(h, h->A + u0 * Np + u0, Np, Lp0 + u0 * Np, Np, Lp0 + u0 * Np, Np, Np - u0, u1 - u0, NB, u0, u0)) ||
+              (rc = flush_stop(h)))
             return rc;
           if (q == 0) {
-            hipEvent_t eU1;
-            if ((rc = next_event(h, &eU1))) return rc;
-            RC_HIP(hipEventRecord(eU1, U1));
+            if (!ext) RC_HIP(hipEventRecord(eU1, U1));
             eU1_prev = eU1;
           }
         } else {                                                  // bulk: everything from u0 on
           if ((rc = next_event(h, &eR_new))) return rc;
           RC_HIP(hipStreamWaitEvent(U2, eG, 0));
           h->launch = U2;
-          if ((rc = rc_launch_syrk_lower(h, h->A + u0 * Np + u0, Np, Lp0 + u0 * Np, Np, Np - u0, NB))) return rc;
-          RC_HIP(hipEventRecord(eR_new, U2));
+          if (ext) h->launch_stop = eR_new;
+          if ((rc = rc_launch_syrk_lower(h, h->A + u0 * Np + u0, Np, Lp0 + u0 * Np, Np, Np - u0, NB)) || (rc = flush_stop(h))) return rc;
+          if (!ext) RC_HIP(hipEventRecord(eR_new, U2));
         }
       }
       eU2_prev = eR_new;

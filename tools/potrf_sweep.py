@@ -13,14 +13,10 @@ from romcomma_amd import _lib                                      # noqa: E402
 from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 KNOBS = [
-    {'RCGP_FINE': '0'},
-    {},
-    {'RCGP_DEPTH': '1'},
-    {'RCGP_DEPTH': '8'},
-    {'RCGP_NB': '256'},
-    {'RCGP_NB': '1024', 'RCGP_DEPTH': '2'},
-    {'RCGP_EXT': '1'},
-    {'RCGP_RESERVE_CUS': '8'},
+    {'RCGP_EXTEV': '0'},
+    {'RCGP_EXTEV': '1'},
+    {'RCGP_EXTEV': '0'},
+    {'RCGP_EXTEV': '1'},
 ]
 
 
