@@ -93,7 +93,9 @@ def main():
                     help="what a rank owns: fold r of an 8-fold split (default, BASELINE configs[4] style) or output column r on a shared "
                          "design (configs[3] style)")
     ap.add_argument('--profile-steps', choices=('all', 'last', 'none'), default='last',
-                    help='timed steps whose kernel launches are bracketed with HIP events (the roofline figures come from those launches)')
+                    help='timed steps whose kernel launches carry HIP events (the roofline figures come from those launches)')
+    ap.add_argument('--profile-every', type=int, default=6,
+                    help='within a profiled step, the evaluations whose launches carry HIP events: every n-th one (1 = all)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group even for one rank (exercises RCCL on a 1-GPU box)')
     args = ap.parse_args()
 
@@ -119,8 +121,10 @@ def main():
     slices = all_slices(M)
     last = {}
 
-    def step():
+    def step(profiled=False):
         fit = fit_lbfgsb(gp, 5.0 * np.ones(M), 2.0, 0.02)
+        if profiled:
+            gp.set_profiling(True)
         V = gp.sobol_closed(slices)
         row = np.concatenate([sobol_indices(V, M), fit['lengthscales'], [fit['variance'], fit['noise'], fit['log_marginal'], fit['nfev']]])
         table = dist.all_gather_rows(row[None, :], world, [rank])      # the one collective: every rank's indices
@@ -133,12 +137,16 @@ def main():
     dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # per-launch HIP events (two per kernel) perturb the panel chain, so by default only the last timed step carries them
-        gp.set_profiling(args.profile_steps == 'all' or (args.profile_steps == 'last' and i == args.steps - 1))
-        step()
+        # Per-launch HIP events cost ~5 % (profiled dispatches, marker packets on the panel chain, harvesting), so by default
+        # they are a SAMPLE of the timed region: the last step, every --profile-every-th evaluation of its fit, and its Sobol pass.
+        profiled = args.profile_steps == 'all' or (args.profile_steps == 'last' and i == args.steps - 1)
+        gp.profile_sample(args.profile_every if profiled else 0)
+        gp.set_profiling(False)
+        step(profiled)
     gp.sync()
     dist.barrier()
     elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    gp.profile_sample(0)
     prof = {name: gp.profile_get(c) for c, name in enumerate(_lib.KERNEL_CLASS_NAMES)}
     gp.set_profiling(False)
 
@@ -179,7 +187,8 @@ def main():
                 'mfma_gemm_family': {'launches': int(n_gemm + n_grad), 'summed_launch_ms': ms_gemm + ms_grad,
                                      'TFLOPs_over_summed_launch_time': family,
                                      'note': 'Cholesky / L^-1 / K^-1 kernels; the Cholesky runs them on 5 streams, so summed launch time exceeds wall time'},
-                'timed_region_ms': 1e3 * elapsed, 'steps_with_hip_events': args.profile_steps},
+                'timed_region_ms': 1e3 * elapsed, 'steps_with_hip_events': args.profile_steps,
+                       'evaluations_with_hip_events': f'every {args.profile_every}-th of a profiled step'},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(N, M, nfev)

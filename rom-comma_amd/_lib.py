@@ -154,6 +154,10 @@ class RcGP:
         return out.value
 
     def lml_grad(self) -> Tuple[float, np.ndarray]:
+        every = getattr(self, '_profile_every', 0)
+        if every:                                        # bench: HIP events around the launches of every n-th evaluation only
+            self.set_profiling(self._profile_count % every == 0)
+            self._profile_count += 1
         out = ctypes.c_double()
         grad = np.empty(self.M + 2)
         self._check(self._lib.rcgp_lml_grad(self._h, ctypes.byref(out), _dp(grad)), 'rcgp_lml_grad')
@@ -250,6 +254,10 @@ class RcGP:
 
     def set_profiling(self, on: bool):
         self._check(self._lib.rcgp_set_profiling(self._h, int(bool(on))), 'rcgp_set_profiling')
+
+    def profile_sample(self, every: int):
+        """Profile the kernel launches of every ``every``-th LML+gradient evaluation from now on (0: leave profiling as it is)."""
+        self._profile_every, self._profile_count = int(every), 0
 
     def profile_reset(self):
         self._check(self._lib.rcgp_profile_reset(self._h), 'rcgp_profile_reset')

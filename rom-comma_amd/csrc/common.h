@@ -44,6 +44,7 @@ struct rcgp_handle_s {
   bool tt_active = false;
   hipStream_t launch = nullptr;      // the stream kernels are currently launched on (stream or stream2)
   hipEvent_t launch_stop = nullptr;  // if set: the next RC_LAUNCH attaches this event to its dispatch (no separate marker packet)
+  int prof_pending = -1;             // index of the profiling bracket whose events the next RC_LAUNCH carries
   bool ext_events = true;            // chain events ride on the kernel dispatches instead of hipEventRecord (RCGP_EXTEV)
   std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing), handed out in order by rc_next_event
   size_t la_cursor = 0;
@@ -108,11 +109,17 @@ struct rcgp_handle_s {
     }                                                                                      \
   } while (0)
 
-// Kernel launch on h->launch. A pending h->launch_stop is recorded by the dispatch itself (hipExtLaunchKernelGGL): on the panel
-// chain that saves one barrier packet per event between two dependent kernels of a queue.
+// Kernel launch on h->launch. Events ride on the dispatch itself (hipExtLaunchKernelGGL) instead of marker packets around it:
+// a pending profiling bracket (RcProfScope with ride = true) contributes its start / stop events, otherwise a pending
+// h->launch_stop (the panel chain's dependency events) is used as the stop event. On the panel chain every packet between two
+// dependent kernels of a queue costs several microseconds.
 #define RC_LAUNCH(kernel, grid, block, lds, ...)                                                              \
   do {                                                                                                       \
-    if (h->launch_stop) {                                                                                    \
+    if (h->prof_pending >= 0) {                                                                              \
+      RcProfEvent& pe_ = h->prof_events[h->prof_pending];                                                    \
+      h->prof_pending = -1;                                                                                  \
+      hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), h->launch, pe_.start, pe_.stop, 0u, __VA_ARGS__); \
+    } else if (h->launch_stop) {                                                                             \
       hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), h->launch, nullptr, h->launch_stop, 0u, __VA_ARGS__); \
       h->launch_stop = nullptr;                                                                              \
     } else {                                                                                                 \
@@ -120,10 +127,11 @@ struct rcgp_handle_s {
     }                                                                                                        \
   } while (0)
 
-// RAII-less profiling bracket: records events around one kernel launch when profiling is on.
+// Profiling bracket of one kernel launch when profiling is on. ride = true: the launcher issues exactly one RC_LAUNCH inside the
+// scope, which carries the two events; otherwise they are recorded around the launch.
 struct RcProfScope {
-  rcgp_handle_s* h; int idx; hipStream_t st;
-  RcProfScope(rcgp_handle_s* h_, int cls, double work) : h(h_), idx(-1), st(h_->launch) {
+  rcgp_handle_s* h; int idx; hipStream_t st; bool ride;
+  RcProfScope(rcgp_handle_s* h_, int cls, double work, bool ride_ = false) : h(h_), idx(-1), st(h_->launch), ride(ride_) {
     if (!h->profiling) return;
     RcProfEvent ev; ev.cls = cls;
     auto take = [&](hipEvent_t* e) {
@@ -131,12 +139,21 @@ struct RcProfScope {
       return hipEventCreate(e) == hipSuccess;
     };
     if (!take(&ev.start) || !take(&ev.stop)) return;
-    (void)hipEventRecord(ev.start, h->launch);
     h->prof_events.push_back(ev);
     idx = (int)h->prof_events.size() - 1;
     h->prof_work[cls] += work;
+    if (ride) h->prof_pending = idx;
+    else (void)hipEventRecord(ev.start, h->launch);
   }
-  ~RcProfScope() { if (idx >= 0) (void)hipEventRecord(h->prof_events[idx].stop, st); }
+  ~RcProfScope() {
+    if (idx < 0) return;
+    if (!ride) (void)hipEventRecord(h->prof_events[idx].stop, st);
+    else if (h->prof_pending == idx) {                          // no launch happened inside the scope: an empty bracket
+      h->prof_pending = -1;
+      (void)hipEventRecord(h->prof_events[idx].start, st);
+      (void)hipEventRecord(h->prof_events[idx].stop, st);
+    }
+  }
 };
 
 // ---- gram.hip

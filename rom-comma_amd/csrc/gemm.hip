@@ -234,7 +234,7 @@ __global__ void RC_BOUNDS(WN) k_syrk_lower(double* __restrict__ C, int64_t ldc, 
 int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk) {
   const int64_t T = n / 128;
   if (T <= 0) return 0;
-  RcProfScope ps(h, RC_K_GEMM, (double)n * (double)(n + 128) * (double)kk);   // 2*kk flops per lower-tile element
+  RcProfScope ps(h, RC_K_GEMM, (double)n * (double)(n + 128) * (double)kk, true);   // 2*kk flops per lower-tile element
   const dim3 grid((unsigned)(T * (T + 1) / 2)), block(128 * RC_WN);
   RC_LAUNCH((k_syrk_lower<RC_WN, 3>), grid, block, 0, C, ldc, P, ldp, (int)kk);
   RC_HIP(hipGetLastError());
@@ -260,7 +260,7 @@ __global__ void RC_BOUNDS(WN) k_gemm_nt_sub(double* __restrict__ C, int64_t ldc,
 int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0) {
   if (m <= 0 || n <= 0) return 0;
-  RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)m * (double)n * (double)kk);
+  RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)m * (double)n * (double)kk, true);
   const dim3 grid((unsigned)(n / 128), (unsigned)(m / 128)), block(128 * RC_WN);
   RC_LAUNCH((k_gemm_nt_sub<RC_WN, 3>), grid, block, 0, C, ldc, A, lda, B, ldb, (int)kk, row0, col0);
   RC_HIP(hipGetLastError());
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(128 * WN) k_prep_next(double* T, double* D, in
 }
 
 int rc_launch_prep_next(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
-  RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0 + 128.0 * 129.0 * 128.0);
+  RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0 + 128.0 * 129.0 * 128.0, true);
   RC_LAUNCH(k_prep_next<RC_WN>, dim3(1), dim3(128 * RC_WN), 0, T, D, ld, invL, rhs, wj);
   RC_HIP(hipGetLastError());
   return 0;
@@ -345,7 +345,7 @@ int rc_launch_prep_next(rcgp_handle_s* h, double* T, double* D, int64_t ld, cons
 
 int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double* invL, int64_t m, double* rhs, const double* wj) {
   if (m <= 0) return 0;
-  RcProfScope ps(h, RC_K_GEMM, (double)m * 128.0 * 128.0);     // triangular: m*128*128 flops algorithmic
+  RcProfScope ps(h, RC_K_GEMM, (double)m * 128.0 * 128.0, true);     // triangular: m*128*128 flops algorithmic
   RC_LAUNCH(k_trsm_panel<RC_WN>, dim3((unsigned)(m / 128)), dim3(128 * RC_WN), 0, P, ldp, invL, rhs, wj);
   RC_HIP(hipGetLastError());
   return 0;

@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
 }
 
 int rc_launch_diag(rcgp_handle_s* h, int64_t j) {
-  RcProfScope ps(h, RC_K_DIAG, 128.0 * 128.0 * 128.0 / 3.0);
+  RcProfScope ps(h, RC_K_DIAG, 128.0 * 128.0 * 128.0 / 3.0, true);
   double* inv = h->invdiag + (j / 128) * 128 * 128;
   if (h->diag_variant == 1) {
     RC_LAUNCH(k_diag, dim3(1), dim3(512), 0, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
