@@ -45,7 +45,8 @@ const char* rcgp_last_error(rcgp_handle h);
 /* Replace the output column (same X): one handle can serve the L independent outputs in turn. */
 int rcgp_set_y(rcgp_handle h, const double* y);
 /* Hyper-parameters in the constrained space: lengthscales ell[M] (pass the isotropic value M times), kernel variance,
- * likelihood (noise) variance. Invalidates any cached factor. */
+ * likelihood (noise) variance. Invalidates any cached factor, unless every value is bit-identical to the current one (the
+ * fit driver sets the optimum again after the last evaluation: nothing is recomputed then). */
 int rcgp_set_hyper(rcgp_handle h, const double* ell, double variance, double noise);
 
 /* Log marginal likelihood at the current hyper-parameters (Gram + Cholesky + forward solve). */

@@ -186,6 +186,9 @@ RC_API int rcgp_set_hyper(rcgp_handle h, const double* ell, double variance, dou
     h->err = "rcgp_set_hyper: variance must be > 0 and noise >= 0";
     return -2;
   }
+  if (h->hyper_set && h->var == variance && h->noise == noise && memcmp(h->ell.data(), ell, (size_t)h->M * sizeof(double)) == 0)
+    return 0;                                    // unchanged: the Gram matrix, its factor and L^-1 stay valid (the fit driver sets
+                                                 // the optimum again after the last evaluation, which is normally at that point)
   h->ell.assign(ell, ell + h->M);
   h->var = variance;
   h->noise = noise;

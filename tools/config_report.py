@@ -32,7 +32,7 @@ def main():
         ell, var, noise = bench_hyper(M)
         gp.set_hyper(ell, var, noise)
         gp.lml_grad()                                             # warm-up: allocations, code objects
-        gp.set_hyper(ell, var, noise)
+        gp.stage_gram()                                           # same hyper-parameters: rebuild K so that the factor is recomputed
         (_, _), t_eval = timed(gp.lml_grad)
         fit, t_fit = timed(lambda: fit_lbfgsb(gp, 5.0 * np.ones(M), 2.0, 0.02))
         slices = [(m, m + 1) for m in range(M)] + [(0, m + 1) for m in range(M)] + [(m + 1, M) for m in range(M)] + [(0, M)]

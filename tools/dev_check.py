@@ -103,7 +103,7 @@ def timings(N, M, reps=3, grad=True, sobol=True):
           f' potrf {tp * 1e3:.2f} ms = {N ** 3 / 3 / tp / 1e12:.2f} TFLOP/s ({N ** 3 / 3 / tp / 78.6e12:.1%} of 78.6)')
     print(f'             lml {gp.lml():.6f}')
     if grad:
-        gp.set_hyper(ell, var, noise)
+        gp.stage_gram()                                # (set_hyper with unchanged values keeps the factor: rebuild K instead)
         t0 = time.perf_counter()
         v, g = gp.lml_grad()
         t1 = time.perf_counter()

@@ -11,8 +11,9 @@ M = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 X, y = synthetic_fold(N, M)
 gp = _lib.RcGP(X, y)
 ell, var, noise = bench_hyper(M)
+gp.set_hyper(ell, var, noise)
 for _ in range(3):
-    gp.set_hyper(ell, var, noise)
+    gp.stage_gram()                                # set_hyper with unchanged values keeps the factor: rebuild K instead
     v, g = gp.lml_grad()
 print('lml', v, g[:2])
 gp.close()
