@@ -637,6 +637,8 @@ int rc_potrf(rcgp_handle_s* h) {
   const int64_t Np = h->Np, NB = h->nb_outer;
   int rc;
   h->launch = h->stream;
+  h->launch_stop = nullptr;                                        // (an earlier call may have failed half-way)
+  h->prof_pending = -1;
   RC_HIP(hipMemcpyAsync(h->w, h->y, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   RC_HIP(hipMemsetAsync(h->info, 0, sizeof(int), h->stream));
   const int64_t npanels = (Np + NB - 1) / NB;
