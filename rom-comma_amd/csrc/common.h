@@ -30,8 +30,8 @@ struct RcProfEvent { hipEvent_t start, stop; int cls; };
 struct rcgp_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;      // main stream: every public call is ordered on it
-  hipStream_t stream2 = nullptr;     // high-priority side stream: look-ahead panel factorisation inside rc_potrf
-  hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky (normal priority)
+  hipStream_t stream2 = nullptr;     // high-priority side stream: the chain of diagonal kernels (+ k_prep_next) inside rc_potrf
+  hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky (CU mask: RCGP_RESERVE_CUS CUs left free)
   hipStream_t stream4 = nullptr;     // L^-1 kernels overlapped with the chain-bound tail of the Cholesky (same CU mask as stream3)
   hipStream_t stream5 = nullptr;     // column work of the fine-grained panel chain (T2/G kernels, potrf.hip)
   hipEvent_t ev_inv = nullptr;       // last overlapped L^-1 kernel
@@ -42,11 +42,11 @@ struct rcgp_handle_s {
   std::vector<int> tt_next_pair;     // per level: first pair not yet completed
   std::vector<int> tt_T_rows;        // per level: C-part row tiles of that pair whose T phase is already issued
   bool tt_active = false;
-  hipStream_t launch = nullptr;      // the stream kernels are currently launched on (stream or stream2)
+  hipStream_t launch = nullptr;      // the stream kernels are currently launched on
   hipEvent_t launch_stop = nullptr;  // if set: the next RC_LAUNCH attaches this event to its dispatch (no separate marker packet)
   int prof_pending = -1;             // index of the profiling bracket whose events the next RC_LAUNCH carries
   bool ext_events = true;            // chain events ride on the kernel dispatches instead of hipEventRecord (RCGP_EXTEV)
-  std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing), handed out in order by rc_next_event
+  std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing), handed out in order by next_event (potrf.hip)
   size_t la_cursor = 0;
   bool lookahead = true;
   bool fine_chain = true;            // split every chain step into a critical single-workgroup part and column work (RCGP_FINE)

@@ -2,11 +2,14 @@
 // w = L^-1 y. Replaces tf.linalg.cholesky / triangular_solve inside GPflow's GPR.log_marginal_likelihood
 // (reference call sites gpr/models.py:360, 427-439).
 //
-// Two-level blocking: outer panels of RC_NB_OUTER columns (K of the big MFMA trailing update), inner blocks of 128:
-//   k_diag       : one workgroup factors the 128x128 diagonal block in registers, inverts it, emits w_j and log L_ii
+// Two-level blocking: outer panels of NB columns (K of the big MFMA updates; h->nb_outer, 512), inner blocks of 128:
+//   k_diag2      : one workgroup factors the 128x128 diagonal block in LDS (16-blocked, MFMA), inverts it, emits w_j and log L_ii
+//   k_prep_next  : (gemm.hip) the tile right below it solved, the next diagonal block completed -- the other critical kernel
 //   k_trsm_panel : rows below <- rows below * inv(L_jj)^T  (a GEMM, gemm.hip), rhs update fused
-//   k_gemm_nt_sub: update of the remaining columns of the current outer panel (K = 128)
-//   k_syrk_lower : trailing update with the whole outer panel (K = RC_NB_OUTER)
+//   k_gemm_nt_sub: K = 128 update of the block columns the chain keeps current; K = NB update of the window's column panels
+//   k_syrk_lower : bulk trailing update with the whole outer panel (K = NB)
+// Scheduling (five streams, events only): potrf_fine below; rc_potrf keeps the simpler coarse schedule behind RCGP_FINE=0 and for
+// matrices of one or two panels.
 #include "common.h"
 
 // Newton-refined reciprocal square root (v_rsq_f64 seed): relative error ~1 ulp.
