@@ -219,6 +219,16 @@ __global__ void __launch_bounds__(512, 2) k_diag(double* __restrict__ A, int64_t
 // Storage: S[128][LS] holds L in its lower triangle; the off-diagonal blocks of X = L^-1 live TRANSPOSED in the upper
 // triangle of S, the diagonal 16-blocks of X in Xd. ~150 KB of LDS: runs on one of the CUs the bulk-update stream leaves free.
 // =====================================================================================================================
+#ifdef RC_DIAG_TIMING
+__device__ long long g_diag_t[32];
+#define RC_T(i) do { if (threadIdx.x == 0) g_diag_t[i] = wall_clock64(); } while (0)
+extern "C" __attribute__((visibility("default"))) int rcgp_debug_diag_times(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_t), sizeof(long long) * 32);
+}
+#else
+#define RC_T(i)
+#endif
+
 #define LS 130
 #define XS 18
 
@@ -230,8 +240,12 @@ __device__ __forceinline__ double rl_d(double v, int lane) {      // broadcast l
 
 // Wave 0 only (lane l mirrors row/column l & 15): Cholesky of the 16x16 block at (16c,16c) of S and its inverse.
 // Lane r keeps row r in registers. Per pivot the current column is published through a 16-entry LDS line and read back as
-// wave-uniform broadcasts (one LDS round trip per pivot, no barrier: a wave's LDS operations execute in order).
-__device__ __forceinline__ void pivot_block_16(double* S, double* Xd, double* rsd, double* pcol, int* info, int64_t j0, int c, int lane) {
+// wave-uniform broadcasts (one LDS round trip per pivot, no barrier: a wave's LDS operations execute in order). The line is read
+// in ONE batch of 16-byte loads into registers before any of it is used: left to itself the compiler issues read - wait - two FMAs
+// eight times per pivot, i.e. eight exposed LDS latencies instead of one. The same for the inverse, whose column k of L comes
+// from a transposed 16x16 copy (lt) as one contiguous batch per step.
+__device__ __attribute__((noinline)) void pivot_block_16(double* S, double* Xd, double* rsd, double* pcol, double* lt, int* info, int64_t j0, int c,
+                                               int lane) {
 #ifdef RC_DIAG2_NO_PIVOT
   if (lane < 16) { for (int i = 0; i < 16; ++i) Xd[(c * 16 + i) * XS + lane] = (i == lane) ? 1.0 : 0.0; rsd[16 * c + lane] = 1.0; }
   return;
@@ -239,43 +253,69 @@ __device__ __forceinline__ void pivot_block_16(double* S, double* Xd, double* rs
   const int r = lane & 15;
   double* blk = S + (16 * c) * LS + 16 * c;
   double a[16], rsv[16];
+  if (c == 0) RC_T(24);
 #pragma unroll
   for (int j = 0; j < 16; ++j) a[j] = (j <= r) ? blk[r * LS + j] : 0.0;
+  if (c == 0) RC_T(25);
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     double* line = pcol + (j & 1) * 16;
     line[r] = a[j];                                             // column j (unscaled): entry r from lane r
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    double d = line[j];
-    if (!(d > 0.0)) {
-      if (lane == 0) atomicCAS(info, 0, (int)(j0 + 16 * c + j + 1));
-      d = 1.0;
-    }
-    const double rs = rc_rsqrt(d);
-    rsv[j] = rs;
-    const double tj = a[j] * (rs * rs);                         // L[r][j] / sqrt(d)
-    a[j] *= rs;                                                 // L[r][j]
+    double ln[16];
 #pragma unroll
-    for (int c2 = j + 1; c2 < 16; ++c2) a[c2] = __builtin_fma(-tj, line[c2], a[c2]);
+    for (int q = j >> 1; q < 8; ++q) {
+      const double2 v = *reinterpret_cast<const double2*>(line + 2 * q);
+      ln[2 * q] = v.x;
+      ln[2 * q + 1] = v.y;
+    }
+    // The only chain from one pivot to the next is d -> 1/d -> tj -> a[j+1] -> line: the reciprocal gets its own short Newton
+    // sequence (a dependent fp64 op costs ~40 cycles here); 1/sqrt(d), needed for the final scaling and the inverse only, and the
+    // positivity check hang off it.
+    const double draw = ln[j];
+    const bool ok = draw > 0.0;                                 // not positive definite (or NaN): flag the leading minor, go on finite
+    double rd = __builtin_amdgcn_rcp(draw);
+    rd = __builtin_fma(__builtin_fma(-draw, rd, 1.0), rd, rd);
+    rd = __builtin_fma(__builtin_fma(-draw, rd, 1.0), rd, rd);
+    const double tj = a[j] * (ok ? rd : 1.0);                   // L[r][j] / sqrt(d) = A[r][j] / d
+#pragma unroll
+    for (int c2 = j + 1; c2 < 16; ++c2) a[c2] = __builtin_fma(-tj, ln[c2], a[c2]);
+    if (!ok && lane == 0) atomicCAS(info, 0, (int)(j0 + 16 * c + j + 1));
+    const double rs = rc_rsqrt(ok ? draw : 1.0);
+    rsv[j] = rs;
+    a[j] *= rs;                                                 // L[r][j]
   }
-  // publish L_cc (rows from lanes 0..15), then invert it: lane j builds column j of X by forward substitution with
-  // wave-uniform reads of L[i][k]
+  if (c == 0) RC_T(26);
+  // publish L_cc (rows from lanes 0..15) and its transpose, then invert it: lane j builds column j of X by forward substitution
+  // with wave-uniform reads of L[i][k]
   if (lane < 16) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) blk[r * LS + j] = (j <= r) ? a[j] : 0.0;
+    for (int j = 0; j < 16; ++j) {
+      blk[r * LS + j] = (j <= r) ? a[j] : 0.0;
+      lt[j * 16 + r] = (j <= r) ? a[j] : 0.0;                   // lt[k][i] = L[i][k]
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   double x[16];
+  if (c == 0) RC_T(27);
 #pragma unroll
   for (int i = 0; i < 16; ++i) x[i] = (i == r) ? 1.0 : 0.0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {                                  // column-oriented: the dependent chain is 16 steps, not 120
+    double lk[16];
+#pragma unroll
+    for (int q = (k + 1) >> 1; q < 8; ++q) {
+      const double2 v = *reinterpret_cast<const double2*>(lt + k * 16 + 2 * q);
+      lk[2 * q] = v.x;
+      lk[2 * q + 1] = v.y;
+    }
     x[k] *= rsv[k];
 #pragma unroll
-    for (int i = k + 1; i < 16; ++i) x[i] = __builtin_fma(-blk[i * LS + k], x[k], x[i]);
+    for (int i = k + 1; i < 16; ++i) x[i] = __builtin_fma(-lk[i], x[k], x[i]);
   }
+  if (c == 0) RC_T(28);
   if (lane < 16) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) Xd[(c * 16 + i) * XS + r] = (i >= r) ? x[i] : 0.0;      // Xd[c][i][j = r]
@@ -291,15 +331,6 @@ __device__ __forceinline__ double xval(const double* S, const double* Xd, int i,
   return ((i >> 4) == (j >> 4)) ? Xd[((i >> 4) * 16 + (i & 15)) * XS + (j & 15)] : S[j * LS + i];
 }
 
-#ifdef RC_DIAG_TIMING
-__device__ long long g_diag_t[32];
-#define RC_T(i) do { if (threadIdx.x == 0) g_diag_t[i] = wall_clock64(); } while (0)
-extern "C" __attribute__((visibility("default"))) int rcgp_debug_diag_times(long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_t), sizeof(long long) * 32);
-}
-#else
-#define RC_T(i)
-#endif
 
 __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
                                                double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
@@ -308,20 +339,24 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
   double* rsd = Xd + 8 * 16 * XS;
   double* rv = rsd + 128;
   double* pcol = rv + 128;                          // 2 x 16 pivot-column lines
+  double* lt = pcol + 32;                           // 16 x 16: transposed copy of the current diagonal 16-block of L
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   double* At = A + j0 * ld + j0;
   RC_T(0);
-  for (int e = t; e < 128 * 128; e += 512) {
-    const int i = e >> 7, j = e & 127;
-    S[i * LS + j] = (j <= i) ? At[(int64_t)i * ld + j] : 0.0;
+  for (int e = t; e < 128 * 64; e += 512) {          // 16 bytes per lane; pairs entirely above the diagonal are not fetched
+    const int i = e >> 6, j = (e & 63) * 2;
+    double2 v = make_double2(0.0, 0.0);
+    if (j <= i) v = *reinterpret_cast<const double2*>(At + (int64_t)i * ld + j);
+    S[i * LS + j] = v.x;
+    S[i * LS + j + 1] = (j + 1 <= i) ? v.y : 0.0;
   }
   if (t < 128) rv[t] = rhs[j0 + t];
   __syncthreads();
   RC_T(1);
 
   // ------------------------------------------------------------------ blocked Cholesky
-  if (wave == 0) pivot_block_16(S, Xd, rsd, pcol, info, j0, 0, lane);
+  if (wave == 0) pivot_block_16(S, Xd, rsd, pcol, lt, info, j0, 0, lane);
   __syncthreads();
   RC_T(2);
 #pragma unroll 1
@@ -364,7 +399,7 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) S[(16 * rb + fq + 4 * q) * LS + 16 * cb + fr] = acc[q];
-        if (tile == 0) pivot_block_16(S, Xd, rsd, pcol, info, j0, c + 1, lane);   // wave 0 only (tile 0 belongs to wave 0)
+        if (tile == 0) pivot_block_16(S, Xd, rsd, pcol, lt, info, j0, c + 1, lane);   // wave 0 only (tile 0 belongs to wave 0)
       }
     }
     __syncthreads();
@@ -372,9 +407,9 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
   }
 
   // L back to global (lower + diagonal, zeros above), log-diagonal
-  for (int e = t; e < 128 * 128; e += 512) {
-    const int i = e >> 7, j = e & 127;
-    At[(int64_t)i * ld + j] = (j <= i) ? S[i * LS + j] : 0.0;
+  for (int e = t; e < 128 * 64; e += 512) {
+    const int i = e >> 6, j = (e & 63) * 2;
+    *reinterpret_cast<double2*>(At + (int64_t)i * ld + j) = make_double2((j <= i) ? S[i * LS + j] : 0.0, (j + 1 <= i) ? S[i * LS + j + 1] : 0.0);
   }
   if (t < 128) logdiag[j0 + t] = -log(rsd[t]);
   RC_T(19);
@@ -443,9 +478,9 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
 
 #endif
   // X out (row-major, zeros above the diagonal) and w_j = X * rhs_j
-  for (int e = t; e < 128 * 128; e += 512) {
-    const int i = e >> 7, j = e & 127;
-    invL[e] = (j <= i) ? xval(S, Xd, i, j) : 0.0;
+  for (int e = t; e < 128 * 64; e += 512) {
+    const int i = e >> 6, j = (e & 63) * 2;
+    *reinterpret_cast<double2*>(invL + i * 128 + j) = make_double2((j <= i) ? xval(S, Xd, i, j) : 0.0, (j + 1 <= i) ? xval(S, Xd, i, j + 1) : 0.0);
   }
   {
     const int i = t >> 2, h4 = t & 3;                // 4 threads per row
@@ -464,7 +499,7 @@ int rc_launch_diag(rcgp_handle_s* h, int64_t j) {
   if (h->diag_variant == 1) {
     RC_LAUNCH(k_diag, dim3(1), dim3(512), 0, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
   } else {
-    const size_t lds = (size_t)(128 * LS + 8 * 16 * XS + 256 + 32) * sizeof(double);
+    const size_t lds = (size_t)(128 * LS + 8 * 16 * XS + 256 + 32 + 256) * sizeof(double);
     if (!h->diag_attr_set) {                                   // per handle = per device (the attribute is device state)
       RC_HIP(hipFuncSetAttribute((const void*)k_diag2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       h->diag_attr_set = true;

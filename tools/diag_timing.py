@@ -26,6 +26,7 @@ for c in range(8):
     names[3 + 2 * c] = f'panel {c}'
     names[4 + 2 * c] = f'trailing {c} + pivot {c + 1}'
 names.update({19: 'store L, logdiag', 20: 'inverse level 16', 21: 'inverse level 32', 22: 'inverse level 64', 23: 'store X, w'})
+print('pivot block 0 inside: load rows %.2f, 16 pivots %.2f, publish %.2f, inverse %.2f us' % tuple((t[k+1]-t[k])/100.0 for k in (24,25,26,27)))
 prev = 0.0
 for i in sorted(names):
     if t[i] == 0:

@@ -14,11 +14,7 @@ from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 KNOBS = [
     {},
-    {'RCGP_NB': '1024', 'RCGP_DEPTH': '2'},
-    {'RCGP_NB': '768', 'RCGP_DEPTH': '3'},
-    {'RCGP_DEPTH': '2'},
-    {'RCGP_DEPTH': '6'},
-    {'RCGP_RESERVE_CUS': '8'},
+    {'RCGP_DIAG': '1'},
     {},
 ]
 
