@@ -356,11 +356,40 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
   RC_T(1);
 
   // ------------------------------------------------------------------ blocked Cholesky
-  if (wave == 0) pivot_block_16(S, Xd, rsd, pcol, lt, info, j0, 0, lane);
-  __syncthreads();
-  RC_T(2);
+  // Iteration c: (a) trailing update with block column c-1 of the lower tiles (rb, cb), c <= cb <= rb -- tile (c, c) goes to
+  // wave 0, which then factors that pivot block while the other waves finish the remaining tiles; (b) panel below the pivot block.
+  // (One call site for the pivot block: inlined twice it cost 180 B of scratch per lane.)
 #pragma unroll 1
   for (int c = 0; c < 8; ++c) {
+    const int cp = c - 1, nb = 8 - c;               // previous block column; remaining block rows/cols
+    const int ntiles = (c > 0) ? nb * (nb + 1) / 2 : 0;
+    auto trailing_tile = [&](int tile) {
+      // tile 0 = (c, c); enumerate the lower triangle row by row
+      int rr = 0, acc_t = tile;
+      while (acc_t > rr) { acc_t -= rr + 1; ++rr; }
+      const int rb = c + rr, cb = c + acc_t;
+      v4d acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = S[(16 * rb + fq + 4 * q) * LS + 16 * cb + fr];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = 4 * s + fq;
+        const double av = -S[(16 * rb + fr) * LS + 16 * cp + k];         // -L_{rb,cp}[i][k]
+        const double bv = S[(16 * cb + fr) * LS + 16 * cp + k];          // B[k][j] = L_{cb,cp}[j][k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[(16 * rb + fq + 4 * q) * LS + 16 * cb + fr] = acc[q];
+    };
+    if (wave == 0) {
+      if (ntiles > 0) trailing_tile(0);
+      pivot_block_16(S, Xd, rsd, pcol, lt, info, j0, c, lane);
+      for (int tile = 8; tile < ntiles; tile += 8) trailing_tile(tile);
+    } else {
+      for (int tile = wave; tile < ntiles; tile += 8) trailing_tile(tile);
+    }
+    __syncthreads();
+    RC_T(2 + 2 * c);
     // (b) panel: L_rc = S_rc * Xcc^T, r = c+1..7, one tile per wave round-robin
     for (int rb = c + 1 + wave; rb < 8; rb += 8) {
       v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -376,34 +405,6 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
     }
     __syncthreads();
     RC_T(3 + 2 * c);
-    if (c == 7) break;
-    // (c) trailing update of the lower tiles (rb, cb), c < cb <= rb. Tile (c+1,c+1) goes to wave 0, which then factors the
-    //     next pivot block while the other waves finish the remaining tiles.
-    {
-      const int nb = 7 - c;                         // remaining block rows/cols
-      const int ntiles = nb * (nb + 1) / 2;
-      for (int tile = wave; tile < ntiles; tile += 8) {
-        // tile 0 = (c+1, c+1); enumerate lower triangle row by row
-        int rr = 0, acc_t = tile;
-        while (acc_t > rr) { acc_t -= rr + 1; ++rr; }
-        const int rb = c + 1 + rr, cb = c + 1 + acc_t;
-        v4d acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = S[(16 * rb + fq + 4 * q) * LS + 16 * cb + fr];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int k = 4 * s + fq;
-          const double av = -S[(16 * rb + fr) * LS + 16 * c + k];        // -L_rc[i][k]
-          const double bv = S[(16 * cb + fr) * LS + 16 * c + k];         // B[k][j] = L_{cb,c}[j][k]
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) S[(16 * rb + fq + 4 * q) * LS + 16 * cb + fr] = acc[q];
-        if (tile == 0) pivot_block_16(S, Xd, rsd, pcol, lt, info, j0, c + 1, lane);   // wave 0 only (tile 0 belongs to wave 0)
-      }
-    }
-    __syncthreads();
-    RC_T(4 + 2 * c);
   }
 
   // L back to global (lower + diagonal, zeros above), log-diagonal
@@ -417,60 +418,74 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
 #ifndef RC_DIAG2_NO_INVERSE
   // ------------------------------------------------------------------ inverse by recursive doubling
   // level sb (block size in 16-blocks): pairs p; A part = block rows [2p*sb, 2p*sb+sb), C part = the next sb block rows.
+  // A wave's second tile (level 64 only) takes the mirrored column, so that every wave gets the same total k-range; the eight
+  // operands of a k-block are fetched from LDS as one batch before its four MFMAs (one exposed LDS latency per k-block, not four).
 #pragma unroll 1
   for (int sb = 1; sb <= 4; sb *= 2) {
     const int npairs = 4 / sb, tiles_per_pair = sb * sb, ntiles = npairs * tiles_per_pair;
+    auto tile_of = [&](int n, int& rb, int& cb) {
+      const int tile = (n == 0) ? wave : 8 + (wave & 4) + (3 - (wave & 3));
+      const int p = tile / tiles_per_pair, w = tile - p * tiles_per_pair;
+      rb = 2 * p * sb + sb + w / sb;
+      cb = 2 * p * sb + w % sb;
+      return tile < ntiles;
+    };
+    const int ntw = (ntiles > 8) ? 2 : 1;
     // phase 1: T_{r,c} = sum_{k in A part, k >= c} L_{r,k} * Ainv_{k,c}  -> stored (transposed) in the X_{r,c} slot
     v4d tacc[2];
-    int nt = 0;
-    for (int tile = wave; tile < ntiles; tile += 8, ++nt) {
-      const int p = tile / tiles_per_pair, w = tile - p * tiles_per_pair;
-      const int rb = 2 * p * sb + sb + w / sb, cb = 2 * p * sb + w % sb;
+    for (int n = 0; n < ntw; ++n) {
+      int rb, cb;
+      if (!tile_of(n, rb, cb)) continue;
+      const int kend = (cb / (2 * sb)) * 2 * sb + sb;             // end of the A part of this pair
       v4d acc = {0.0, 0.0, 0.0, 0.0};
-      for (int kb = cb; kb < 2 * p * sb + sb; ++kb) {
+      for (int kb = cb; kb < kend; ++kb) {
+        double av[4], bv[4];
+        const double* bsrc = (kb == cb) ? Xd + (kb * 16 + fq) * XS + fr : S + (16 * cb + fr) * LS + 16 * kb + fq;   // Ainv_{kb,cb}[k][j]
+        const int bstep = (kb == cb) ? 4 * XS : 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int k = 4 * s + fq;
-          const double av = S[(16 * rb + fr) * LS + 16 * kb + k];                      // L_{r,kb}[i][k]
-          const double bv = xval(S, Xd, 16 * kb + k, 16 * cb + fr);                    // Ainv_{kb,cb}[k][j]
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          av[s] = S[(16 * rb + fr) * LS + 16 * kb + 4 * s + fq];                        // L_{r,kb}[i][k]
+          bv[s] = bsrc[s * bstep];
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
       }
-      tacc[nt] = acc;
+      tacc[n] = acc;
     }
     __syncthreads();                                  // nobody reads the target slots during phase 1, but keep phases apart
-    nt = 0;
-    for (int tile = wave; tile < ntiles; tile += 8, ++nt) {
-      const int p = tile / tiles_per_pair, w = tile - p * tiles_per_pair;
-      const int rb = 2 * p * sb + sb + w / sb, cb = 2 * p * sb + w % sb;
+    for (int n = 0; n < ntw; ++n) {
+      int rb, cb;
+      if (!tile_of(n, rb, cb)) continue;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) S[(16 * cb + fr) * LS + 16 * rb + fq + 4 * q] = tacc[nt][q];   // T[i][j] at S[j][i]
+      for (int q = 0; q < 4; ++q) S[(16 * cb + fr) * LS + 16 * rb + fq + 4 * q] = tacc[n][q];   // T[i][j] at S[j][i]
     }
     __syncthreads();
     // phase 2: X_{r,c} = - sum_{k in C part, k <= r} Cinv_{r,k} * T_{k,c}
-    nt = 0;
-    for (int tile = wave; tile < ntiles; tile += 8, ++nt) {
-      const int p = tile / tiles_per_pair, w = tile - p * tiles_per_pair;
-      const int rb = 2 * p * sb + sb + w / sb, cb = 2 * p * sb + w % sb;
+    for (int n = 0; n < ntw; ++n) {
+      int rb, cb;
+      if (!tile_of(n, rb, cb)) continue;
+      const int kbeg = (cb / (2 * sb)) * 2 * sb + sb;             // start of the C part of this pair
       v4d acc = {0.0, 0.0, 0.0, 0.0};
-      for (int kb = 2 * p * sb + sb; kb <= rb; ++kb) {
+      for (int kb = kbeg; kb <= rb; ++kb) {
+        double av[4], bv[4];
+        const double* asrc = (kb == rb) ? Xd + (rb * 16 + fr) * XS + fq : S + (16 * kb + fq) * LS + 16 * rb + fr;   // Cinv_{r,kb}[i][k]
+        const int astep = (kb == rb) ? 4 : 4 * LS;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int k = 4 * s + fq;
-          const double av = -xval(S, Xd, 16 * rb + fr, 16 * kb + k);                   // -Cinv_{r,kb}[i][k] (zero above its diagonal)
-          const double bv = S[(16 * cb + fr) * LS + 16 * kb + k];                      // T_{kb,cb}[k][j] at S[j][k]
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          av[s] = -asrc[s * astep];
+          bv[s] = S[(16 * cb + fr) * LS + 16 * kb + 4 * s + fq];                        // T_{kb,cb}[k][j] at S[j][k]
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
       }
-      tacc[nt] = acc;
+      tacc[n] = acc;
     }
     __syncthreads();
-    nt = 0;
-    for (int tile = wave; tile < ntiles; tile += 8, ++nt) {
-      const int p = tile / tiles_per_pair, w = tile - p * tiles_per_pair;
-      const int rb = 2 * p * sb + sb + w / sb, cb = 2 * p * sb + w % sb;
+    for (int n = 0; n < ntw; ++n) {
+      int rb, cb;
+      if (!tile_of(n, rb, cb)) continue;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) S[(16 * cb + fr) * LS + 16 * rb + fq + 4 * q] = tacc[nt][q];
+      for (int q = 0; q < 4; ++q) S[(16 * cb + fr) * LS + 16 * rb + fq + 4 * q] = tacc[n][q];
     }
     __syncthreads();
     RC_T(20 + (sb == 1 ? 0 : sb == 2 ? 1 : 2));
