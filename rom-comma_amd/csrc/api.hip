@@ -35,6 +35,7 @@ static void free_all(rcgp_handle_s* h) {
   h->la_events.clear();
   if (h->ev_inv) { (void)hipEventDestroy(h->ev_inv); h->ev_inv = nullptr; }
   if (h->stream4) { (void)hipStreamDestroy(h->stream4); h->stream4 = nullptr; }
+  if (h->stream6) { (void)hipStreamDestroy(h->stream6); h->stream6 = nullptr; }
   if (h->stream5) { (void)hipStreamDestroy(h->stream5); h->stream5 = nullptr; }
   if (h->stream3) { (void)hipStreamDestroy(h->stream3); h->stream3 = nullptr; }
   if (h->stream2) { (void)hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
@@ -62,6 +63,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     RC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // hi is the numerically lowest = highest priority
     RC_HIP(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
     RC_HIP(hipStreamCreateWithPriority(&h->stream5, hipStreamNonBlocking, hi));
+    RC_HIP(hipStreamCreateWithPriority(&h->stream6, hipStreamNonBlocking, hi));
   }
   {
     // The bulk-update stream may use every CU except the first RCGP_RESERVE_CUS, which stay free for the panel chain.
@@ -106,6 +108,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     if (x >= 1 && x <= 16) h->chain_ext = x;
   }
   if (const char* e = getenv("RCGP_EXTEV")) h->ext_events = (e[0] != '0');
+  if (const char* e = getenv("RCGP_SPLIT")) h->chain_split = (e[0] != '0');
   if (const char* e = getenv("RCGP_INV_EVERY")) {
     const int x = atoi(e);
     if (x >= 1) h->inv_every = x;

@@ -34,6 +34,8 @@ struct rcgp_handle_s {
   hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky (CU mask: RCGP_RESERVE_CUS CUs left free)
   hipStream_t stream4 = nullptr;     // L^-1 kernels overlapped with the chain-bound tail of the Cholesky (same CU mask as stream3)
   hipStream_t stream5 = nullptr;     // column work of the fine-grained panel chain (T2/G kernels, potrf.hip)
+  hipStream_t stream6 = nullptr;     // the far part of that column work (block columns the next chain step does not read)
+  bool chain_split = true;           // near / far split of the chain's column update (RCGP_SPLIT)
   hipEvent_t ev_inv = nullptr;       // last overlapped L^-1 kernel
   bool overlap_ok = false;            // RCGP_OVERLAP_INVERSE=1 overlaps L^-1 with the Cholesky tail (measured SLOWER: long L^-1 tiles hold the
                                       // CUs the panel chain needs: 109 vs 85 ms per evaluation at C2), so it is off
@@ -52,8 +54,8 @@ struct rcgp_handle_s {
   bool fine_chain = true;            // split every chain step into a critical single-workgroup part and column work (RCGP_FINE)
   int64_t nb_outer = RC_NB_OUTER;    // outer panel width (RCGP_NB)
   int inv_every = 8;                 // with overlap_inverse: L^-1 kernels are fed every inv_every panels (RCGP_INV_EVERY)
-  int chain_depth = 4;               // column panels updated by their own kernels ahead of the bulk trailing update (RCGP_DEPTH >= 1)
-  int chain_ext = 2;                 // 128-blocks past its own panel that a chain step keeps up to date (RCGP_EXT >= 1)
+  int chain_depth = 2;               // column panels updated by their own kernels ahead of the bulk trailing update (RCGP_DEPTH >= 1)
+  int chain_ext = 4;                 // 128-blocks past its own panel that a chain step keeps up to date (RCGP_EXT >= 1)
   bool diag_attr_set = false;
   int diag_variant = 2;              // 2 = MFMA 16-blocked kernel (k_diag2), 1 = register column sweep (k_diag)
   int64_t N = 0, Np = 0;       // rows, rows padded to a multiple of RC_TILE

@@ -585,7 +585,11 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
   RC_HIP(hipEventRecord(e0, h->stream));
   RC_HIP(hipStreamWaitEvent(C, e0, 0));
   RC_HIP(hipStreamWaitEvent(B, e0, 0));
-  hipEvent_t eG_prev = nullptr, eU1_prev = nullptr, eU2_prev = nullptr;
+  hipEvent_t eG_prev = nullptr, eU1_prev = nullptr, eU2_prev = nullptr, eFar_prev = nullptr;
+  hipStream_t B2 = h->stream6;
+  RC_HIP(hipStreamWaitEvent(B2, e0, 0));
+  bool near_waited = false, far_waited = false;                  // this panel's wait for the previous panel's window piece
+  int64_t u0_prev = 0;                                           // first column of that piece
   const bool ext = h->ext_events && !h->profiling;              // (the profiling bracket records its own events around a launch)
   for (int64_t j = 0; j < Np; j += 128) {
     const int64_t below = Np - (j + 128);
@@ -609,7 +613,44 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     if ((rc = rc_launch_prep_next(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j)) || (rc = flush_stop(h))) return rc;
     if (!ext) RC_HIP(hipEventRecord(eP, C));
     h->launch = B;
-    if (below > 128) {
+    hipEvent_t ePanel = eG;                                       // everything of this step on B (and B2) done
+    if (below > 128 && h->chain_split) {
+      // G(j) in two kernels: the two block columns the NEXT chain step reads (near, on B; P(j+1) waits for it alone) and the
+      // rest (far, on B2, in order behind the earlier far updates). Only the far part, and the near part once it reaches the
+      // columns of the previous panel's window piece, wait for that piece: the chain does not stop at a panel boundary.
+      hipEvent_t eT2, eFar;
+      if ((rc = next_event(h, &eT2))) return rc;
+      if (ext) h->launch_stop = eT2;
+      if ((rc = rc_launch_trsm_panel(h, P + 128 * Np, Np, inv, below - 128, h->w + j + 256, h->w + j)) || (rc = flush_stop(h))) return rc;
+      if (!ext) RC_HIP(hipEventRecord(eT2, B));
+      const int64_t c0 = j + 128, nend = (c0 + 256 < cend) ? c0 + 256 : cend;
+      RC_HIP(hipStreamWaitEvent(B, eP, 0));
+      if (eFar_prev) RC_HIP(hipStreamWaitEvent(B, eFar_prev, 0));
+      if (eU1_prev && !near_waited && nend > u0_prev) { RC_HIP(hipStreamWaitEvent(B, eU1_prev, 0)); near_waited = true; }
+      if (ext) h->launch_stop = eG;
+      if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + c0, Np, P + 128 * Np, Np, P, Np, below - 128, nend - c0, 128, j + 256, c0)) ||
+          (rc = flush_stop(h)))
+        return rc;
+      if (!ext) RC_HIP(hipEventRecord(eG, B));
+      if (cend > nend) {
+        if ((rc = next_event(h, &eFar))) return rc;
+        RC_HIP(hipStreamWaitEvent(B2, eT2, 0));
+        if (eU1_prev && !far_waited && cend > u0_prev) { RC_HIP(hipStreamWaitEvent(B2, eU1_prev, 0)); far_waited = true; }
+        h->launch = B2;
+        if (ext) h->launch_stop = eFar;
+        if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + nend, Np, P + 128 * Np, Np, P + (nend - c0) * Np, Np, below - 128, cend - nend,
+                                        128, j + 256, nend)) ||
+            (rc = flush_stop(h)))
+          return rc;
+        if (!ext) RC_HIP(hipEventRecord(eFar, B2));
+        eFar_prev = eFar;
+      }
+      if (j + 128 == pend) {                                      // the outer updates need both halves
+        if ((rc = next_event(h, &ePanel))) return rc;
+        if (eFar_prev) RC_HIP(hipStreamWaitEvent(B, eFar_prev, 0));
+        RC_HIP(hipEventRecord(ePanel, B));
+      }
+    } else if (below > 128) {
       if ((rc = rc_launch_trsm_panel(h, P + 128 * Np, Np, inv, below - 128, h->w + j + 256, h->w + j))) return rc;
       if (first_of_panel && eU1_prev) RC_HIP(hipStreamWaitEvent(B, eU1_prev, 0));
       RC_HIP(hipStreamWaitEvent(B, eP, 0));
@@ -624,6 +665,9 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     }
     eG_prev = eG;
     if (j + 128 == pend) {                                        // panel [pend - NB, pend) is final once B has finished this step
+      const hipEvent_t eG = ePanel;                               // (shadows: the outer updates wait for the whole step)
+      near_waited = far_waited = false;
+      u0_prev = pend + EXT;
       // Outer (K = NB) updates with the finished panel, by target column panel: the next `depth` (shifted) panels one kernel
       // each, in column order on the main stream -- the first one is what the chain is waiting for -- and everything beyond
       // them in one bulk kernel on the CU-masked stream. A column panel leaves the bulk kernel's domain one panel before the
@@ -670,12 +714,14 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     }
   }
   h->launch = h->stream;
-  hipEvent_t eC, eB;
-  if ((rc = next_event(h, &eC)) || (rc = next_event(h, &eB))) return rc;
+  hipEvent_t eC, eB, eB2;
+  if ((rc = next_event(h, &eC)) || (rc = next_event(h, &eB)) || (rc = next_event(h, &eB2))) return rc;
   RC_HIP(hipEventRecord(eC, C));
   RC_HIP(hipEventRecord(eB, B));
+  RC_HIP(hipEventRecord(eB2, B2));
   RC_HIP(hipStreamWaitEvent(h->stream, eC, 0));
   RC_HIP(hipStreamWaitEvent(h->stream, eB, 0));
+  RC_HIP(hipStreamWaitEvent(h->stream, eB2, 0));
   if (eU2_prev) RC_HIP(hipStreamWaitEvent(h->stream, eU2_prev, 0));
   if (overlap_inverse) {
     RC_HIP(hipEventRecord(h->ev_inv, h->stream4));

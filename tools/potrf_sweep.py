@@ -13,9 +13,14 @@ from romcomma_amd import _lib                                      # noqa: E402
 from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 KNOBS = [
-    {},
-    {'RCGP_DIAG': '1'},
-    {},
+    {'RCGP_SPLIT': '0', 'RCGP_EXT': '2'},
+    {'RCGP_EXT': '4', 'RCGP_DEPTH': '1'},
+    {'RCGP_EXT': '4', 'RCGP_DEPTH': '2'},
+    {'RCGP_EXT': '4', 'RCGP_DEPTH': '3'},
+    {'RCGP_EXT': '3', 'RCGP_DEPTH': '2'},
+    {'RCGP_EXT': '3', 'RCGP_DEPTH': '3'},
+    {'RCGP_EXT': '6', 'RCGP_DEPTH': '2'},
+    {'RCGP_SPLIT': '0', 'RCGP_EXT': '2'},
 ]
 
 
