@@ -186,7 +186,7 @@ def main():
                 'sobol': {'launches': int(n_sob), 'total_ms': ms_sob, 'Gexp_per_s': sob_exps / (ms_sob * 1e-3) / 1e9 if ms_sob > 0 else 0.0},
                 'mfma_gemm_family': {'launches': int(n_gemm + n_grad), 'summed_launch_ms': ms_gemm + ms_grad,
                                      'TFLOPs_over_summed_launch_time': family,
-                                     'note': 'Cholesky / L^-1 / K^-1 kernels; the Cholesky runs them on 5 streams, so summed launch time exceeds wall time'},
+                                     'note': 'Cholesky / L^-1 / K^-1 kernels; the Cholesky runs them on several streams, so summed launch time exceeds wall time'},
                 'timed_region_ms': 1e3 * elapsed, 'steps_with_hip_events': args.profile_steps,
                        'evaluations_with_hip_events': f'every {args.profile_every}-th of a profiled step'},
         }

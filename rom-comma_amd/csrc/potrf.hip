@@ -8,7 +8,7 @@
 //   k_trsm_panel : rows below <- rows below * inv(L_jj)^T  (a GEMM, gemm.hip), rhs update fused
 //   k_gemm_nt_sub: K = 128 update of the block columns the chain keeps current; K = NB update of the window's column panels
 //   k_syrk_lower : bulk trailing update with the whole outer panel (K = NB)
-// Scheduling (five streams, events only): potrf_fine below; rc_potrf keeps the simpler coarse schedule behind RCGP_FINE=0 and for
+// Scheduling (main stream + chain + two column-work streams + bulk, events only): potrf_fine below; rc_potrf keeps the simpler coarse schedule behind RCGP_FINE=0 and for
 // matrices of one or two panels.
 #include "common.h"
 
