@@ -13,10 +13,17 @@ from romcomma_amd import _lib                                      # noqa: E402
 from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 KNOBS = [
+    {'RCGP_FINE': '0'},
+    {'RCGP_SPLIT': '0', 'RCGP_EXT': '2', 'RCGP_DEPTH': '4'},
     {},
-    {'RCGP_OVERLAP_INVERSE': '1', 'RCGP_INV_EVERY': '2', 'RCGP_INV_CAP': '1024', 'RCGP_RESERVE_CUS_INV': '0'},
-    {'RCGP_OVERLAP_INVERSE': '1', 'RCGP_INV_EVERY': '4', 'RCGP_INV_CAP': '2048', 'RCGP_RESERVE_CUS_INV': '0'},
-    {'RCGP_OVERLAP_INVERSE': '1', 'RCGP_INV_EVERY': '8', 'RCGP_INV_CAP': '4096', 'RCGP_RESERVE_CUS_INV': '0'},
+    {'RCGP_DEPTH': '1'},
+    {'RCGP_DEPTH': '4'},
+    {'RCGP_EXT': '2'},
+    {'RCGP_EXT': '6'},
+    {'RCGP_NB': '256'},
+    {'RCGP_NB': '1024'},
+    {'RCGP_EXTEV': '0'},
+    {'RCGP_DIAG': '1'},
     {},
 ]
 
