@@ -229,7 +229,7 @@ def test_exp_accuracy_through_gram(gpu):
 # BASELINE.json sizes: size-independent properties (the oracle cannot run these in seconds)
 # --------------------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize('N,M', [(8192, 5), (16384, 10)])
+@pytest.mark.parametrize('N,M', [(8192, 5), (16384, 10), (28672, 20)])      # BASELINE configs[1], [2] and one fold of [4]
 def test_full_size_properties(gpu, N, M):
     X, y = o.synthetic_fold(N, M)
     ell, var, noise = o.bench_hyper(M)
