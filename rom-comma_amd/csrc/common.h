@@ -35,6 +35,8 @@ struct rcgp_handle_s {
   hipStream_t stream4 = nullptr;     // L^-1 kernels overlapped with the chain-bound tail of the Cholesky (same CU mask as stream3)
   hipStream_t stream5 = nullptr;     // column work of the fine-grained panel chain (T2/G kernels, potrf.hip)
   hipStream_t stream6 = nullptr;     // the far part of that column work (block columns the next chain step does not read)
+  bool prep_split = true;            // the chain's critical step as k_prep1 + k_prep2 on several CUs instead of k_prep_next on one (RCGP_PSPLIT)
+  bool prep_attr_set = false;
   bool chain_split = true;           // near / far split of the chain's column update (RCGP_SPLIT)
   hipEvent_t ev_inv = nullptr;       // last overlapped L^-1 kernel
   bool overlap_ok = false;            // RCGP_OVERLAP_INVERSE=1 overlaps L^-1 with the Cholesky tail (measured SLOWER: long L^-1 tiles hold the
@@ -175,6 +177,8 @@ int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double*
 // critical step of the fine-grained chain, one workgroup: T (128 x 128, below the diagonal block) <- T * invL^T,
 // rhs (128) -= T_new * wj, then D (the next diagonal block) -= T_new * T_new^T
 int rc_launch_prep_next(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
+// the same in two kernels on 8 + 10 compute units (k_prep1 solves the tile, k_prep2 updates the diagonal block)
+int rc_launch_prep_split(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
 // L^-1 by recursive doubling, level s: T = B * Ainv (lower-tri Ainv) for C-part row tiles [ti0, ti0+nti) of pairs
 // [pair0, pair0+npairs); X21 = -Cinv * T for whole pairs
 int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti0, int nti);

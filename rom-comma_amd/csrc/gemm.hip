@@ -336,6 +336,137 @@ __global__ void __launch_bounds__(128 * WN) k_prep_next(double* T, double* D, in
   acc_store<WN>(acc, D, ld);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same critical step on SEVERAL compute units (one workgroup cannot issue fp64 MFMAs faster than ~1 per 110 cycles and
+// SIMD): k_prep1 solves the tile in eight 16-row strips (one workgroup each, the triangular inverse in LDS, only the k <= j
+// part of every product), k_prep2 updates the lower 32x32 blocks of the next diagonal block from the solved tile.
+// Operands sit in LDS with an odd row stride (LP): the 16 lanes of a fragment read are 16 rows of one k.
+// ---------------------------------------------------------------------------------------------------------------------
+#define LP 129
+__global__ void __launch_bounds__(256) k_prep1(double* T, int64_t ld, const double* __restrict__ invL, double* rhs,
+                                               const double* __restrict__ wj) {
+  extern __shared__ double sm1[];                  // Inv[128][LP], Ts[16][LP], wv[128], red[4][16]
+  double* Inv = sm1;
+  double* Ts = Inv + 128 * LP;
+  double* wv = Ts + 16 * LP;
+  double* red = wv + 128;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
+  const int r0 = 16 * blockIdx.x;
+  for (int e = t; e < 128 * 64; e += 256) {         // rows of inv below the strip's reach are never used: j < 128 always needed
+    const int i = e >> 6, j2 = (e & 63) * 2;
+    double2 v = make_double2(0.0, 0.0);
+    if (j2 <= i) v = *reinterpret_cast<const double2*>(invL + i * 128 + j2);
+    Inv[i * LP + j2] = v.x;
+    Inv[i * LP + j2 + 1] = v.y;
+  }
+  for (int e = t; e < 16 * 64; e += 256) {
+    const int i = e >> 6, j2 = (e & 63) * 2;
+    const double2 v = *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2);
+    Ts[i * LP + j2] = v.x;
+    Ts[i * LP + j2 + 1] = v.y;
+  }
+  if (t < 128) wv[t] = wj[t];
+  __syncthreads();
+  double part[4] = {0.0, 0.0, 0.0, 0.0};           // this wave's share of (strip row fq + 4q) . wj
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int jt = (n == 0) ? wave : 7 - wave;      // column tiles jt and 7 - jt: 9 k-blocks per wave
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kt = 0; kt <= jt; ++kt) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        av[s2] = Ts[fr * LP + 16 * kt + 4 * s2 + fq];
+        bv[s2] = Inv[(16 * jt + fr) * LP + 16 * kt + 4 * s2 + fq];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
+    }
+    const double w = wv[16 * jt + fr];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      T[(int64_t)(r0 + fq + 4 * q) * ld + 16 * jt + fr] = acc[q];
+      part[q] = __builtin_fma(acc[q], w, part[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double v = part[q];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    if (fr == 0) red[wave * 16 + fq + 4 * q] = v;
+  }
+  __syncthreads();
+  if (t < 16) rhs[r0 + t] -= (red[t] + red[16 + t]) + (red[32 + t] + red[48 + t]);
+}
+
+__global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, double* D, int64_t ld) {
+  extern __shared__ double sm2[];                  // La[32][LP], Lb[32][LP]
+  double* La = sm2;
+  double* Lb = La + 32 * LP;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
+  int bi = 0, rem = blockIdx.x;                     // lower 32x32 blocks of the 4x4 block grid, row by row
+  while (rem > bi) { rem -= bi + 1; ++bi; }
+  const int bj = rem;
+  for (int e = t; e < 32 * 64; e += 256) {
+    const int i = e >> 6, j2 = (e & 63) * 2;
+    const double2 va = *reinterpret_cast<const double2*>(Lt + (int64_t)(32 * bi + i) * ld + j2);
+    const double2 vb = *reinterpret_cast<const double2*>(Lt + (int64_t)(32 * bj + i) * ld + j2);
+    La[i * LP + j2] = va.x;
+    La[i * LP + j2 + 1] = va.y;
+    Lb[i * LP + j2] = vb.x;
+    Lb[i * LP + j2 + 1] = vb.y;
+  }
+  const int ti = wave >> 1, tj = wave & 1;
+  double* Dt = D + (int64_t)(32 * bi + 16 * ti) * ld + 32 * bj + 16 * tj;
+  const bool needed = !(bi == bj && tj > ti);       // the strictly upper 16x16 tile of a diagonal block is never read
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  if (needed) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = Dt[(int64_t)(fq + 4 * q) * ld + fr];
+  }
+  __syncthreads();
+  if (needed) {
+#pragma unroll 2
+    for (int kt = 0; kt < 8; ++kt) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        av[s2] = -La[(16 * ti + fr) * LP + 16 * kt + 4 * s2 + fq];
+        bv[s2] = Lb[(16 * tj + fr) * LP + 16 * kt + 4 * s2 + fq];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Dt[(int64_t)(fq + 4 * q) * ld + fr] = acc[q];
+  }
+}
+
+// T solved and rhs rows updated (k_prep1, which carries a pending h->launch_stop: the column work only needs the solved tile),
+// then the next diagonal block updated (k_prep2).
+int rc_launch_prep_split(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
+  const size_t lds1 = (size_t)(128 * LP + 16 * LP + 128 + 64) * sizeof(double), lds2 = (size_t)(64 * LP) * sizeof(double);
+  if (!h->prep_attr_set) {
+    RC_HIP(hipFuncSetAttribute((const void*)k_prep1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    RC_HIP(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    h->prep_attr_set = true;
+  }
+  {
+    RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
+    RC_LAUNCH(k_prep1, dim3(8), dim3(256), lds1, T, ld, invL, rhs, wj);
+    RC_HIP(hipGetLastError());
+  }
+  {
+    RcProfScope ps(h, RC_K_GEMM, 128.0 * 129.0 * 128.0, true);
+    RC_LAUNCH(k_prep2, dim3(10), dim3(256), lds2, (const double*)T, D, ld);
+    RC_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
 int rc_launch_prep_next(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
   RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0 + 128.0 * 129.0 * 128.0, true);
   RC_LAUNCH(k_prep_next<RC_WN>, dim3(1), dim3(128 * RC_WN), 0, T, D, ld, invL, rhs, wj);

@@ -609,8 +609,12 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     RC_HIP(hipStreamWaitEvent(B, eD, 0));
     if (eG_prev) RC_HIP(hipStreamWaitEvent(C, eG_prev, 0));
     if (first_of_panel && eU1_prev && h->chain_ext < 2) RC_HIP(hipStreamWaitEvent(C, eU1_prev, 0));   // P touches column j + 128 >= u0
-    if (ext) h->launch_stop = eP;
-    if ((rc = rc_launch_prep_next(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j)) || (rc = flush_stop(h))) return rc;
+    if (ext) h->launch_stop = eP;                                 // (with the split: taken by k_prep1 -- the column work needs the solved tile only)
+    if (h->prep_split)
+      rc = rc_launch_prep_split(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j);
+    else
+      rc = rc_launch_prep_next(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j);
+    if (rc || (rc = flush_stop(h))) return rc;
     if (!ext) RC_HIP(hipEventRecord(eP, C));
     h->launch = B;
     hipEvent_t ePanel = eG;                                       // everything of this step on B (and B2) done

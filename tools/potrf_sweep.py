@@ -23,6 +23,7 @@ KNOBS = [
     {'RCGP_NB': '256'},
     {'RCGP_NB': '1024'},
     {'RCGP_EXTEV': '0'},
+    {'RCGP_PSPLIT': '0'},
     {'RCGP_DIAG': '1'},
     {},
 ]
