@@ -10,7 +10,7 @@
 #define RC_TILE 128            // edge of a workgroup tile and of a diagonal Cholesky block
 #define RC_BK 16               // k-depth of one LDS stage of the MFMA GEMM
 #define RC_MAX_M 64            // largest input dimensionality supported by the fused kernels
-#define RC_NB_OUTER 512        // outer panel width of the blocked Cholesky (K of the trailing update)
+#define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 

@@ -745,7 +745,7 @@ int rc_potrf(rcgp_handle_s* h) {
   RC_HIP(hipMemcpyAsync(h->w, h->y, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   RC_HIP(hipMemsetAsync(h->info, 0, sizeof(int), h->stream));
   const int64_t npanels = (Np + NB - 1) / NB;
-  const bool la = h->lookahead && npanels > 2;
+  const bool la = h->lookahead && Np >= 4 * 128;                   // (the multi-stream schedule needs no minimum number of panels)
   const bool inv = la && h->overlap_inverse;                      // feed L^-1 kernels into the idle CUs of the chain-bound tail
   h->tt_active = false;                                            // any earlier incremental schedule is void: L is being rebuilt
   h->la_cursor = 0;

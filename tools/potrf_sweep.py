@@ -21,7 +21,7 @@ KNOBS = [
     {'RCGP_EXT': '2'},
     {'RCGP_EXT': '6'},
     {'RCGP_NB': '256'},
-    {'RCGP_NB': '1024'},
+    {'RCGP_NB': '512'},
     {'RCGP_EXTEV': '0'},
     {'RCGP_PSPLIT': '0'},
     {'RCGP_DIAG': '1'},
