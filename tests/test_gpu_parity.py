@@ -136,6 +136,36 @@ def test_set_y_switches_output_without_reupload(gpu):
     gp.close()
 
 
+def test_set_hyper_with_unchanged_values_keeps_the_factor(gpu):
+    """The fit driver sets the optimum again after its last evaluation: bit-identical hyper-parameters must not cost another
+    Cholesky, and anything else (another value, another y) must."""
+    import time
+    N, M = 2048, 3
+    X, y = o.synthetic_fold(N, M, k=4)
+    ell, var, noise = np.array([1.0, 1.5, 2.0]), 1.2, 0.01
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(ell, var, noise)
+    lml, grad = gp.lml_grad()
+    t0 = time.perf_counter()
+    gp.set_hyper(ell.copy(), var, noise)
+    again = gp.lml()
+    dt_cached = time.perf_counter() - t0
+    assert again == lml
+    gp.set_hyper(ell, var, noise * (1 + 1e-9))                    # anything different invalidates
+    assert gp.lml() != lml
+    gp.set_hyper(ell, var, noise)
+    t0 = time.perf_counter()
+    fresh = gp.lml()
+    dt_fresh = time.perf_counter() - t0
+    assert fresh == pytest.approx(lml, rel=1e-13)
+    assert dt_cached < 0.5 * dt_fresh                             # no Gram + Cholesky behind the cached call
+    y2 = o.synthetic_fold(N, M, k=4, l=1)[1]
+    gp.set_y(y2)
+    gp.set_hyper(ell, var, noise)                                 # unchanged hyper-parameters, but y changed: recompute
+    assert gp.lml() == pytest.approx(o.lml(X, y2, ell, var, noise), rel=1e-10)
+    gp.close()
+
+
 def test_predict_chunking_and_ragged_counts(gpu):
     X, y = o.synthetic_fold(500, 3, k=2)
     ell = np.array([0.8, 1.6, 2.4])
