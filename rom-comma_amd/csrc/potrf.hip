@@ -273,7 +273,7 @@ __device__ __attribute__((noinline)) void pivot_block_16(double* S, double* Xd, 
     // The only chain from one pivot to the next is d -> 1/d -> tj -> a[j+1] -> line: the reciprocal gets its own short Newton
     // sequence (a dependent fp64 op costs ~40 cycles here); 1/sqrt(d), needed for the final scaling and the inverse only, and the
     // positivity check hang off it.
-    const double draw = ln[j];
+    const double draw = rl_d(a[j], j);                          // = line[j], without waiting for the LDS round trip
     const bool ok = draw > 0.0;                                 // not positive definite (or NaN): flag the leading minor, go on finite
     double rd = __builtin_amdgcn_rcp(draw);
     rd = __builtin_fma(__builtin_fma(-draw, rd, 1.0), rd, rd);
