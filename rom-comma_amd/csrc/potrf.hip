@@ -565,17 +565,21 @@ static int next_event(rcgp_handle_s* h, hipEvent_t* out) {
 }
 
 // Fine-grained blocked Cholesky. The critical path of the factorisation is the sequence of 128x128 diagonal blocks;
-// everything else only has to be ready one step (or one panel) later. Per 128-column block j, on four streams:
-//   C  (h->stream2, high priority): D(j) = diagonal kernel; P(j) = k_prep_next: tile (j+1, j) solved, block (j+1, j+1) updated.
-//                                   D(j+1) follows P(j) in stream order, so a chain step costs D + P, not D + T + G.
+// everything else only has to be ready one step (or one panel) later. Per 128-column block j, on five streams:
+//   C  (h->stream2, high priority): D(j) = diagonal kernel; P(j) = the tile (j+1, j) solved and the block (j+1, j+1) updated
+//                                   (k_prep1 + k_prep2 on several CUs, or k_prep_next on one). D(j+1) follows P(j) in stream
+//                                   order, so a chain step costs D + P, not D + T + G.
 //   B  (h->stream5, high priority): T2(j) = panel solve of the rows from block j+2 on (after D(j));
-//                                   G(j)  = K=128 update of block columns [j+1, cend) for the rows from block j+2 on (after P(j));
-//                                   P(j+1) waits for G(j), which has had the whole of D(j+1) to finish.
-//   U1 (h->stream, main)          : when panel p = [pend-NB, pend) is complete, the K=NB update of the NB columns from u0 on
+//                                   near G(j) = K=128 update of the two block columns j+1, j+2 -- all that P(j+1) reads -- for the
+//                                   rows from block j+2 on (after the solved tile of P(j) and the far part of G(j-1));
+//   B2 (h->stream6, high priority): far G(j) = the same update of the block columns [j+3, cend) (after T2(j), in stream order
+//                                   behind the earlier far parts; it is the far part that waits for the window piece below).
+//   U1 (h->stream, main)          : when panel p = [pend-NB, pend) is complete, its K=NB update of the next `depth` column panels
+//                                   from u0 on, one kernel each, nearest first (window pieces);
 //   U2 (h->stream3, CU-masked)    : ... and of everything beyond them (the bulk of the flops), concurrently with the next chain.
 // cend = pend + EXT: the G updates reach EXT columns past their own panel, so the first blocks of the NEXT panel are already
-// up to date when the chain arrives there (u0 = pend + EXT) and the chain never waits at a panel boundary: U1(p) only has to
-// finish before G of the first block of panel p+1.
+// up to date when the chain arrives there (u0 = pend + EXT): the chain itself never waits for a window piece, only the far part
+// (and the near part once it reaches column u0) does. Events ride on the dispatches (RC_LAUNCH, h->launch_stop).
 static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
   const int64_t Np = h->Np, NB = h->nb_outer, EXT = 128 * (int64_t)h->chain_ext;
   hipStream_t C = h->stream2, B = h->stream5, U1 = h->stream, U2 = h->stream3;
