@@ -35,7 +35,7 @@ struct rcgp_handle_s {
   hipStream_t stream4 = nullptr;     // L^-1 kernels overlapped with the chain-bound tail of the Cholesky (same CU mask as stream3)
   hipStream_t stream5 = nullptr;     // column work of the fine-grained panel chain (T2/G kernels, potrf.hip)
   hipStream_t stream6 = nullptr;     // the far part of that column work (block columns the next chain step does not read)
-  bool prep_split = true;            // the chain's critical step as k_prep1 + k_prep2 on several CUs instead of k_prep_next on one (RCGP_PSPLIT)
+  int prep_split = 2;                // the chain's critical step as k_prep1 + k_prep2 on several CUs (2: k_prep1 with 8 waves, 1: 4 waves) instead of k_prep_next on one (0) (RCGP_PSPLIT)
   bool prep_attr_set = false;
   bool chain_split = true;           // near / far split of the chain's column update (RCGP_SPLIT)
   hipEvent_t ev_inv = nullptr;       // last overlapped L^-1 kernel

@@ -343,23 +343,25 @@ __global__ void __launch_bounds__(128 * WN) k_prep_next(double* T, double* D, in
 // Operands sit in LDS with an odd row stride (LP): the 16 lanes of a fragment read are 16 rows of one k.
 // ---------------------------------------------------------------------------------------------------------------------
 #define LP 129
-__global__ void __launch_bounds__(256) k_prep1(double* T, int64_t ld, const double* __restrict__ invL, double* rhs,
-                                               const double* __restrict__ wj) {
-  extern __shared__ double sm1[];                  // Inv[128][LP], Ts[16][LP], wv[128], red[4][16]
+// NW = 4: column tiles w and 7 - w per wave (9 k-blocks each); NW = 8: tile w per wave, twice the loads in flight.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_prep1(double* T, int64_t ld, const double* __restrict__ invL, double* rhs,
+                                                   const double* __restrict__ wj) {
+  extern __shared__ double sm1[];                  // Inv[128][LP], Ts[16][LP], wv[128], red[NW][16]
   double* Inv = sm1;
   double* Ts = Inv + 128 * LP;
   double* wv = Ts + 16 * LP;
   double* red = wv + 128;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
   const int r0 = 16 * blockIdx.x;
-  for (int e = t; e < 128 * 64; e += 256) {         // rows of inv below the strip's reach are never used: j < 128 always needed
+  for (int e = t; e < 128 * 64; e += 64 * NW) {         // rows of inv below the strip's reach are never used: j < 128 always needed
     const int i = e >> 6, j2 = (e & 63) * 2;
     double2 v = make_double2(0.0, 0.0);
     if (j2 <= i) v = *reinterpret_cast<const double2*>(invL + i * 128 + j2);
     Inv[i * LP + j2] = v.x;
     Inv[i * LP + j2 + 1] = v.y;
   }
-  for (int e = t; e < 16 * 64; e += 256) {
+  for (int e = t; e < 16 * 64; e += 64 * NW) {
     const int i = e >> 6, j2 = (e & 63) * 2;
     const double2 v = *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2);
     Ts[i * LP + j2] = v.x;
@@ -369,8 +371,8 @@ __global__ void __launch_bounds__(256) k_prep1(double* T, int64_t ld, const doub
   __syncthreads();
   double part[4] = {0.0, 0.0, 0.0, 0.0};           // this wave's share of (strip row fq + 4q) . wj
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int jt = (n == 0) ? wave : 7 - wave;      // column tiles jt and 7 - jt: 9 k-blocks per wave
+  for (int n = 0; n < 8 / NW; ++n) {
+    const int jt = (n == 0) ? wave : 7 - wave;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     for (int kt = 0; kt <= jt; ++kt) {
       double av[4], bv[4];
@@ -399,7 +401,11 @@ __global__ void __launch_bounds__(256) k_prep1(double* T, int64_t ld, const doub
     if (fr == 0) red[wave * 16 + fq + 4 * q] = v;
   }
   __syncthreads();
-  if (t < 16) rhs[r0 + t] -= (red[t] + red[16 + t]) + (red[32 + t] + red[48 + t]);
+  if (t < 16) {
+    double v = (red[t] + red[16 + t]) + (red[32 + t] + red[48 + t]);
+    if (NW == 8) v += (red[64 + t] + red[80 + t]) + (red[96 + t] + red[112 + t]);
+    rhs[r0 + t] -= v;
+  }
 }
 
 __global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, double* D, int64_t ld) {
@@ -448,15 +454,20 @@ __global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, do
 // T solved and rhs rows updated (k_prep1, which carries a pending h->launch_stop: the column work only needs the solved tile),
 // then the next diagonal block updated (k_prep2).
 int rc_launch_prep_split(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
-  const size_t lds1 = (size_t)(128 * LP + 16 * LP + 128 + 64) * sizeof(double), lds2 = (size_t)(64 * LP) * sizeof(double);
+  const size_t lds1 = (size_t)(128 * LP + 16 * LP + 128 + 128) * sizeof(double), lds2 = (size_t)(64 * LP) * sizeof(double);
   if (!h->prep_attr_set) {
-    RC_HIP(hipFuncSetAttribute((const void*)k_prep1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    RC_HIP(hipFuncSetAttribute((const void*)k_prep1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    RC_HIP(hipFuncSetAttribute((const void*)k_prep1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     RC_HIP(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     h->prep_attr_set = true;
   }
   {
     RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
-    RC_LAUNCH(k_prep1, dim3(8), dim3(256), lds1, T, ld, invL, rhs, wj);
+    if (h->prep_split == 2) {
+      RC_LAUNCH(k_prep1<8>, dim3(8), dim3(512), lds1, T, ld, invL, rhs, wj);
+    } else {
+      RC_LAUNCH(k_prep1<4>, dim3(8), dim3(256), lds1, T, ld, invL, rhs, wj);
+    }
     RC_HIP(hipGetLastError());
   }
   {

@@ -24,6 +24,7 @@ KNOBS = [
     {'RCGP_NB': '512'},
     {'RCGP_EXTEV': '0'},
     {'RCGP_PSPLIT': '0'},
+    {'RCGP_PSPLIT': '1'},
     {'RCGP_DIAG': '1'},
     {},
 ]
@@ -69,6 +70,9 @@ def run(N, M, knobs, reps=5):
 
 if __name__ == '__main__':
     args = [int(a) for a in sys.argv[1:]] or [8192, 5, 16384, 10]
+    if os.environ.get('SWEEP_KNOBS'):                               # e.g. SWEEP_KNOBS='[{}, {"RCGP_PSPLIT": "2"}, {}]'
+        import json
+        KNOBS = json.loads(os.environ['SWEEP_KNOBS'])
     for i in range(0, len(args), 2):
         for kn in KNOBS:
             run(args[i], args[i + 1], kn)
