@@ -89,6 +89,31 @@ int rcgp_sobol_cross(rcgp_handle h, const double* ell_j, double var_j, const dou
 int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var_a, const double* alpha_a, int n_slices, const int32_t* slices,
                            double* phi_d, double* psi_d, double* phi_m, double* psi_m);
 
+/* ---- covariant (dependent multi-output) GP: the reference's romcomma.gpf path ----
+ * One GP over L outputs sharing the N training inputs (gpf/models.py:33-139). System index a = l * N + n, output-major, as
+ * the reference stacks Y (gpf/models.py:120). Kernel (gpf/kernels.py:93-104, 153-154) and likelihood (gpf/likelihoods.py:61-64):
+ *   K[(l,n),(j,n')] = F[l][j] exp(-1/2 sum_m (x_nm / ell[l][m] - x_n'm / ell[j][m])^2) + Sigma[l][j] [n == n'].
+ * rcgp_lml, rcgp_factor, rcgp_get_k_inv_y (L*N values = the reference's (L,1,N)), rcgp_get_k_cho / rcgp_get_gram ((L*N)^2),
+ * rcgp_set_y (Y as N x L) and the stage / profiling entries work on such a handle; the single-output entries
+ * (rcgp_set_hyper, rcgp_lml_grad, rcgp_predict, rcgp_predict_gradient, rcgp_sobol_closed/cross/error_terms) return -2. */
+int rcgp_create_mo(rcgp_handle* out, int device, int64_t N, int M, int L, const double* X /* N x M */, const double* Y /* N x L */);
+/* ell (L x M), F and Sigma (L x L, symmetric; diag(F) > 0). */
+int rcgp_set_hyper_mo(rcgp_handle h, const double* ell, const double* F, const double* Sigma);
+/* LML and its partial derivatives with every entry of ell, F and Sigma treated as independent (the caller applies the
+ * Cholesky parametrisation of gpf/base.py:32-96 and the transforms): g_ell (L x M), g_F and g_Sigma (L x L, symmetric). */
+int rcgp_lml_grad_mo(rcgp_handle h, double* lml, double* g_ell, double* g_F, double* g_Sigma);
+/* MOGPR.predict_f / predict_y without full covariances (gpf/models.py:84-113, gpr/models.py:377-384): mean and SD as (n, L). */
+int rcgp_predict_mo(rcgp_handle h, int64_t n, const double* Xnew, int include_noise, double* mean, double* sd);
+/* Closed-form Sobol with a non-diagonal F (gsa/calibrators.py:60-97 with is_F_diagonal false) works on "virtual outputs"
+ * p = (l, J): phi_p = 1/(ell_l ell_J + 1), pre_p = F[l][J] sqrt(prod_m ell_lm ell_Jm phi_pm), alpha_p = K_inv_Y[J]. Weight vector
+ * g_p[n] = pre_p exp(-1/2 sum_m phi_pm x_nm^2) alpha_p[n] - shift_p, the shift being the mean over (J, n) for that l (:90).
+ * rcgp_sobol_weight_sum returns sum_n of the unshifted g_p; rcgp_sobol_pair returns, for every slice, the pair form
+ * sum_{n,n'} g_a[n] g_b[n'] prod_{m in slice} h_m(n,n'); V_lj is its sum over the virtual outputs (l, .) x (j, .) (:79).
+ * Both only use the handle's design matrix X (any handle on the same X will do). */
+int rcgp_sobol_weight_sum(rcgp_handle h, const double* phi /* M */, double pre, const double* alpha /* N */, double* sum);
+int rcgp_sobol_pair(rcgp_handle h, const double* phi_a, double pre_a, const double* alpha_a, double shift_a, const double* phi_b,
+                    double pre_b, const double* alpha_b, double shift_b, int n_slices, const int32_t* slices, double* V);
+
 /* ---- stage-level entry points used by bench.py and the kernel tests ---- */
 int rcgp_stage_gram(rcgp_handle h);      /* Z = X/ell; A = K + noise I (lower tiles) */
 int rcgp_stage_potrf(rcgp_handle h);     /* blocked Cholesky in place + w = L^-1 y; requires rcgp_stage_gram */

@@ -37,6 +37,14 @@ SIGNATURES = {
     'rcgp_sobol_cross': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_int, _c_int32_p, _c_double_p]),
     'rcgp_sobol_error_terms': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_int, _c_int32_p, _c_double_p,
                                               _c_double_p, _c_double_p, _c_double_p]),
+    'rcgp_create_mo': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p,
+                                      _c_double_p]),
+    'rcgp_set_hyper_mo': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
+    'rcgp_lml_grad_mo': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'rcgp_predict_mo': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    'rcgp_sobol_weight_sum': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p]),
+    'rcgp_sobol_pair': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
+                                       _c_double_p, ctypes.c_double, ctypes.c_int, _c_int32_p, _c_double_p]),
     'rcgp_stage_gram': (ctypes.c_int, [ctypes.c_void_p]),
     'rcgp_stage_potrf': (ctypes.c_int, [ctypes.c_void_p]),
     'rcgp_stage_trtri': (ctypes.c_int, [ctypes.c_void_p]),
@@ -267,6 +275,90 @@ class RcGP:
         self._check(self._lib.rcgp_profile_get(self._h, int(cls), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work)),
                     'rcgp_profile_get')
         return n.value, ms.value, work.value
+
+
+class RcMOGP(RcGP):
+    """One covariant GP over L outputs (the reference's romcomma.gpf.models.MOGPR) resident on one GPU. The (L N) axis of
+    ``k_inv_y`` / ``k_cho`` / ``gram`` is output-major."""
+
+    def __init__(self, X: np.ndarray, Y: np.ndarray, device: int = 0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        X = _f64(X)
+        Y = _f64(Y)
+        if X.ndim != 2 or Y.ndim != 2 or Y.shape[0] != X.shape[0]:
+            raise ValueError('X must be (N, M) and Y (N, L)')
+        (self.N, self.M), self.L = X.shape, Y.shape[1]
+        rc = self._lib.rcgp_create_mo(ctypes.byref(self._h), int(device), self.N, self.M, self.L, _dp(X), _dp(Y))
+        if rc != 0:
+            msg = self._lib.rcgp_last_error(None).decode()
+            self._h = ctypes.c_void_p()
+            raise RcgpError(f'rcgp_create_mo failed ({rc}): {msg}')
+        self.device = int(device)
+
+    def set_y(self, Y):
+        Y = _f64(Y, (self.N, self.L))
+        self._check(self._lib.rcgp_set_y(self._h, _dp(Y)), 'rcgp_set_y')
+
+    def set_hyper(self, ell, F, Sigma):
+        ell = np.ascontiguousarray(np.broadcast_to(np.asarray(ell, dtype=np.float64), (self.L, self.M)))
+        F, Sigma = _f64(F, (self.L, self.L)), _f64(Sigma, (self.L, self.L))
+        self._check(self._lib.rcgp_set_hyper_mo(self._h, _dp(ell), _dp(F), _dp(Sigma)), 'rcgp_set_hyper_mo')
+
+    def lml_grad(self) -> Tuple[float, np.ndarray, np.ndarray, np.ndarray]:
+        """(lml, d/dF (L, L), d/dell (L, M), d/dSigma (L, L)), every entry treated as an independent variable."""
+        out = ctypes.c_double()
+        g_ell, g_F, g_S = np.empty((self.L, self.M)), np.empty((self.L, self.L)), np.empty((self.L, self.L))
+        self._check(self._lib.rcgp_lml_grad_mo(self._h, ctypes.byref(out), _dp(g_ell), _dp(g_F), _dp(g_S)), 'rcgp_lml_grad_mo')
+        return out.value, g_F, g_ell, g_S
+
+    def k_inv_y(self) -> np.ndarray:
+        out = np.empty((self.L, 1, self.N))
+        self._check(self._lib.rcgp_get_k_inv_y(self._h, _dp(out)), 'rcgp_get_k_inv_y')
+        return out
+
+    def k_cho(self) -> np.ndarray:
+        out = np.empty((self.L * self.N, self.L * self.N))
+        self._check(self._lib.rcgp_get_k_cho(self._h, _dp(out)), 'rcgp_get_k_cho')
+        return out
+
+    def gram(self) -> np.ndarray:
+        out = np.empty((self.L * self.N, self.L * self.N))
+        self._check(self._lib.rcgp_get_gram(self._h, _dp(out)), 'rcgp_get_gram')
+        return out
+
+    def predict(self, Xnew, include_noise: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        Xnew = _f64(Xnew)
+        if Xnew.ndim != 2 or Xnew.shape[1] != self.M:
+            raise ValueError('Xnew must be (n, M)')
+        n = Xnew.shape[0]
+        mean, sd = np.empty((n, self.L)), np.empty((n, self.L))
+        self._check(self._lib.rcgp_predict_mo(self._h, n, _dp(Xnew), int(bool(include_noise)), _dp(mean), _dp(sd)), 'rcgp_predict_mo')
+        return mean, sd
+
+    def predict_gradient(self, Xnew):
+        raise NotImplementedError('predict_gradient is not available for a covariant GP on this backend')
+
+    def sobol_closed(self, slices):
+        raise NotImplementedError('use sobol_covariant on a covariant GP')
+
+    sobol_cross = sobol_error_terms = sobol_closed
+
+
+def sobol_weight_sum(gp: RcGP, phi, pre: float, alpha) -> float:
+    phi, alpha = _f64(phi, (gp.M,)), _f64(alpha, (gp.N,))
+    out = ctypes.c_double()
+    gp._check(gp._lib.rcgp_sobol_weight_sum(gp._h, _dp(phi), float(pre), _dp(alpha), ctypes.byref(out)), 'rcgp_sobol_weight_sum')
+    return out.value
+
+
+def sobol_pair(gp: RcGP, phi_a, pre_a: float, alpha_a, shift_a: float, phi_b, pre_b: float, alpha_b, shift_b: float, slices) -> np.ndarray:
+    s = RcGP._slices(slices)
+    phi_a, phi_b, alpha_a, alpha_b = _f64(phi_a, (gp.M,)), _f64(phi_b, (gp.M,)), _f64(alpha_a, (gp.N,)), _f64(alpha_b, (gp.N,))
+    V = np.empty(s.shape[0])
+    gp._check(gp._lib.rcgp_sobol_pair(gp._h, _dp(phi_a), float(pre_a), _dp(alpha_a), float(shift_a), _dp(phi_b), float(pre_b), _dp(alpha_b),
+                                      float(shift_b), s.shape[0], s.ctypes.data_as(_c_int32_p), _dp(V)), 'rcgp_sobol_pair')
+    return V
 
 
 def device_count() -> int:

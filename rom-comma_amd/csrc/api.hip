@@ -23,7 +23,7 @@ RC_API int rcgp_device_count(void) {
 
 static void free_all(rcgp_handle_s* h) {
   double** bufs[] = {&h->X, &h->Z, &h->sq, &h->y, &h->w, &h->alpha, &h->A, &h->Linv, &h->S, &h->invdiag, &h->logdiag, &h->partial,
-                     &h->scal, &h->ell_d, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob, &h->gV, &h->gC};
+                     &h->scal, &h->ell_d, &h->FS_d, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob, &h->gV, &h->gC};
   for (auto b : bufs)
     if (*b) { hipFree(*b); *b = nullptr; }
   if (h->info) { hipFree(h->info); h->info = nullptr; }
@@ -49,6 +49,18 @@ RC_API const char* rcgp_last_error(rcgp_handle h) { return h ? h->err.c_str() : 
 static int upload_padded(rcgp_handle_s* h, double* dst, const double* src, int64_t rows, int64_t rows_padded, int cols) {
   RC_HIP(hipMemsetAsync(dst, 0, (size_t)rows_padded * cols * sizeof(double), h->stream));
   RC_HIP(hipMemcpyAsync(dst, src, (size_t)rows * cols * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// Targets: y[N] for one output; Y (N x L, row-major, as the reference's Fold.Y) for a covariant GP, stored output-major
+// (gpf/models.py:120: reshape(transpose(Y), [-1, 1])), every block padded with zeros to Nb rows.
+static int upload_targets(rcgp_handle_s* h, const double* Y) {
+  if (h->L == 1) return upload_padded(h, h->y, Y, h->N, h->Np, 1);
+  std::vector<double> col((size_t)h->Np, 0.0);
+  for (int l = 0; l < h->L; ++l)
+    for (int64_t n = 0; n < h->N; ++n) col[(size_t)l * h->Nb + n] = Y[n * h->L + l];
+  RC_HIP(hipMemcpyAsync(h->y, col.data(), col.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   RC_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -133,27 +145,35 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   RC_HIP(hipMalloc(&h->logdiag, (size_t)Np * sizeof(double)));
   RC_HIP(hipMalloc(&h->scal, 256 * sizeof(double)));
   RC_HIP(hipMalloc(&h->info, sizeof(int)));
-  RC_HIP(hipMalloc(&h->ell_d, (size_t)M * sizeof(double)));
+  RC_HIP(hipMalloc(&h->ell_d, (size_t)h->L * M * sizeof(double)));
+  RC_HIP(hipMalloc(&h->FS_d, (size_t)2 * h->L * h->L * sizeof(double)));
   int rc;
-  if ((rc = upload_padded(h, h->X, X, h->N, Np, M))) return rc;
-  if ((rc = upload_padded(h, h->y, y, h->N, Np, 1))) return rc;
-  return 0;
+  for (int l = 0; l < h->L; ++l)                                   // the same inputs under every output block
+    if ((rc = upload_padded(h, h->X + (size_t)l * h->Nb * M, X, h->N, h->Nb, M))) return rc;
+  return upload_targets(h, y);
 }
 
-RC_API int rcgp_create(rcgp_handle* out, int device, int64_t N, int M, const double* X, const double* y) {
+RC_API int rcgp_create_mo(rcgp_handle* out, int device, int64_t N, int M, int L, const double* X, const double* Y) {
   if (!out) return -1;
   *out = nullptr;
-  if (N < 1 || M < 1 || M > RC_MAX_M || !X || !y) { g_create_error = "rcgp_create: bad argument (need N>=1, 1<=M<=64, X, y)"; return -2; }
+  if (N < 1 || M < 1 || M > RC_MAX_M || L < 1 || L > RC_MAX_L || !X || !Y) {
+    g_create_error = "rcgp_create: bad argument (need N>=1, 1<=M<=64, 1<=L<=16, X, y)";
+    return -2;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "rcgp_create: no HIP device available"; return -4; }
   if (device < 0 || device >= ndev) { g_create_error = "rcgp_create: device index out of range"; return -2; }
   rcgp_handle_s* h = new rcgp_handle_s();
   h->device = device;
   h->N = N;
-  h->Np = ((N + RC_TILE - 1) / RC_TILE) * RC_TILE;
+  h->L = L;
+  h->Nb = ((N + RC_TILE - 1) / RC_TILE) * RC_TILE;
+  h->Np = h->Nb * L;
   h->M = M;
-  h->ell.assign(M, 1.0);
-  int rc = create_impl(h, X, y);
+  h->ell.assign((size_t)L * M, 1.0);
+  h->Fm.assign((size_t)L * L, 0.0);
+  h->Sm.assign((size_t)L * L, 0.0);
+  int rc = create_impl(h, X, Y);
   if (rc) {
     g_create_error = h->err;
     free_all(h);
@@ -162,6 +182,10 @@ RC_API int rcgp_create(rcgp_handle* out, int device, int64_t N, int M, const dou
   }
   *out = h;
   return 0;
+}
+
+RC_API int rcgp_create(rcgp_handle* out, int device, int64_t N, int M, const double* X, const double* y) {
+  return rcgp_create_mo(out, device, N, M, 1, X, y);
 }
 
 RC_API int rcgp_destroy(rcgp_handle h) {
@@ -176,13 +200,56 @@ RC_API int rcgp_destroy(rcgp_handle h) {
 RC_API int rcgp_set_y(rcgp_handle h, const double* y) {
   RC_CHECK_H(h);
   if (!y) { h->err = "rcgp_set_y: null y"; return -2; }
-  int rc = upload_padded(h, h->y, y, h->N, h->Np, 1);
+  int rc = upload_targets(h, y);
   h->factored = h->inverted = false;
   return rc;
 }
 
+static int upload_hyper(rcgp_handle_s* h) {
+  const size_t LL = (size_t)h->L * h->L;
+  std::vector<double> fs(2 * LL);
+  memcpy(fs.data(), h->Fm.data(), LL * sizeof(double));
+  memcpy(fs.data() + LL, h->Sm.data(), LL * sizeof(double));
+  RC_HIP(hipMemcpyAsync(h->ell_d, h->ell.data(), h->ell.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RC_HIP(hipMemcpyAsync(h->FS_d, fs.data(), fs.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  h->hyper_set = true;
+  h->factored = h->inverted = false;
+  return 0;
+}
+
+RC_API int rcgp_set_hyper_mo(rcgp_handle h, const double* ell, const double* F, const double* Sigma) {
+  RC_CHECK_H(h);
+  if (!ell || !F || !Sigma) { h->err = "rcgp_set_hyper_mo: null argument"; return -2; }
+  const int L = h->L, M = h->M;
+  for (int i = 0; i < L * M; ++i)
+    if (!(ell[i] > 0.0) || !isfinite(ell[i])) { h->err = "rcgp_set_hyper_mo: lengthscales must be positive and finite"; return -2; }
+  for (int l = 0; l < L; ++l) {
+    if (!(F[l * L + l] > 0.0) || !(Sigma[l * L + l] >= 0.0)) { h->err = "rcgp_set_hyper_mo: need diag(F) > 0 and diag(Sigma) >= 0"; return -2; }
+    for (int j = 0; j < L; ++j)
+      if (!isfinite(F[l * L + j]) || !isfinite(Sigma[l * L + j]) || F[l * L + j] != F[j * L + l] || Sigma[l * L + j] != Sigma[j * L + l]) {
+        h->err = "rcgp_set_hyper_mo: F and Sigma must be finite and symmetric";
+        return -2;
+      }
+  }
+  const size_t LL = (size_t)L * L;
+  if (h->hyper_set && memcmp(h->ell.data(), ell, h->ell.size() * sizeof(double)) == 0 && memcmp(h->Fm.data(), F, LL * sizeof(double)) == 0 &&
+      memcmp(h->Sm.data(), Sigma, LL * sizeof(double)) == 0)
+    return 0;                                    // unchanged: keep the factor (see rcgp_set_hyper)
+  h->ell.assign(ell, ell + (size_t)L * M);
+  h->Fm.assign(F, F + LL);
+  h->Sm.assign(Sigma, Sigma + LL);
+  h->var = F[0];
+  h->noise = Sigma[0];
+  return upload_hyper(h);
+}
+
+#define RC_SINGLE_OUTPUT(h, name) \
+  if ((h)->L != 1) { (h)->err = name ": single-output entry point called on a covariant (L > 1) handle"; return -2; }
+
 RC_API int rcgp_set_hyper(rcgp_handle h, const double* ell, double variance, double noise) {
   RC_CHECK_H(h);
+  RC_SINGLE_OUTPUT(h, "rcgp_set_hyper");
   if (!ell) { h->err = "rcgp_set_hyper: null ell"; return -2; }
   for (int m = 0; m < h->M; ++m)
     if (!(ell[m] > 0.0) || !isfinite(ell[m])) { h->err = "rcgp_set_hyper: lengthscales must be positive and finite"; return -2; }
@@ -196,11 +263,9 @@ RC_API int rcgp_set_hyper(rcgp_handle h, const double* ell, double variance, dou
   h->ell.assign(ell, ell + h->M);
   h->var = variance;
   h->noise = noise;
-  RC_HIP(hipMemcpyAsync(h->ell_d, h->ell.data(), (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  RC_HIP(hipStreamSynchronize(h->stream));
-  h->hyper_set = true;
-  h->factored = h->inverted = false;
-  return 0;
+  h->Fm[0] = variance;
+  h->Sm[0] = noise;
+  return upload_hyper(h);
 }
 
 static int need_hyper(rcgp_handle_s* h) {
@@ -271,8 +336,20 @@ RC_API int rcgp_lml(rcgp_handle h, double* lml) {
   return rc_lml_value(h, lml);
 }
 
+RC_API int rcgp_lml_grad_mo(rcgp_handle h, double* lml, double* g_ell, double* g_F, double* g_Sigma) {
+  RC_CHECK_H(h);
+  if (!lml || !g_ell || !g_F || !g_Sigma) return -2;
+  int rc;
+  if ((rc = ensure_factor(h, true))) return rc;
+  int nrows = 0;
+  if ((rc = rc_launch_grad_mo(h, &nrows))) return rc;
+  if ((rc = rc_lml_value(h, lml))) return rc;
+  return rc_grad_finish_mo(h, g_ell, g_F, g_Sigma);
+}
+
 RC_API int rcgp_lml_grad(rcgp_handle h, double* lml, double* grad) {
   RC_CHECK_H(h);
+  RC_SINGLE_OUTPUT(h, "rcgp_lml_grad");
   if (!lml || !grad) return -2;
   int rc;
   if ((rc = ensure_factor(h, true))) return rc;
@@ -295,14 +372,20 @@ RC_API int rcgp_get_k_inv_y(rcgp_handle h, double* out) {
   if (!out) return -2;
   int rc;
   if ((rc = rcgp_factor(h))) return rc;
-  RC_HIP(hipMemcpyAsync(out, h->alpha, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipMemcpy2DAsync(out, (size_t)h->N * sizeof(double), h->alpha, (size_t)h->Nb * sizeof(double), (size_t)h->N * sizeof(double),
+                          (size_t)h->L, hipMemcpyDeviceToHost, h->stream));          // L blocks of N: (L, 1, N) of gpr/models.py:444
   RC_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
 
+// The (L N) x (L N) system matrix without the padding rows of each output block
 static int copy_square(rcgp_handle_s* h, double* out) {
-  RC_HIP(hipMemcpy2DAsync(out, (size_t)h->N * sizeof(double), h->A, (size_t)h->Np * sizeof(double), (size_t)h->N * sizeof(double),
-                          (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+  const size_t NT = (size_t)h->N * h->L;
+  for (int bi = 0; bi < h->L; ++bi)
+    for (int bj = 0; bj < h->L; ++bj)
+      RC_HIP(hipMemcpy2DAsync(out + ((size_t)bi * h->N) * NT + (size_t)bj * h->N, NT * sizeof(double),
+                              h->A + ((size_t)bi * h->Nb) * h->Np + (size_t)bj * h->Nb, (size_t)h->Np * sizeof(double),
+                              (size_t)h->N * sizeof(double), (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
   RC_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -315,7 +398,7 @@ RC_API int rcgp_get_k_cho(rcgp_handle h, double* out) {
   double lml;
   if ((rc = rc_lml_value(h, &lml))) return rc;
   if ((rc = copy_square(h, out))) return rc;
-  const int64_t N = h->N;
+  const int64_t N = h->N * h->L;
   for (int64_t i = 0; i < N; ++i) memset(out + i * N + i + 1, 0, (size_t)(N - i - 1) * sizeof(double));
   return 0;
 }
@@ -327,7 +410,7 @@ RC_API int rcgp_get_gram(rcgp_handle h, double* out) {
   if ((rc = need_hyper(h))) return rc;
   if ((rc = do_gram(h))) return rc;
   if ((rc = copy_square(h, out))) return rc;
-  const int64_t N = h->N;
+  const int64_t N = h->N * h->L;
   for (int64_t i = 0; i < N; ++i)
     for (int64_t j = i + 1; j < N; ++j) out[i * N + j] = out[j * N + i];
   return 0;
@@ -363,37 +446,53 @@ int rc_ensure_pred(rcgp_handle_s* h) {
   return 0;
 }
 
-RC_API int rcgp_predict(rcgp_handle h, int64_t n, const double* Xnew, int include_noise, double* mean, double* sd) {
-  RC_CHECK_H(h);
-  if (n < 0 || (n > 0 && (!Xnew || !mean || !sd))) { h->err = "rcgp_predict: bad argument"; return -2; }
+// Posterior of output `out` at n points; results strided by the number of outputs (mean[o * L + out]).
+static int predict_output(rcgp_handle_s* h, int64_t n, const double* Xnew, int include_noise, int out, double* mean, double* sd) {
   int rc;
-  if ((rc = rcgp_factor(h))) return rc;
-  const int M = h->M;
+  const int M = h->M, L = h->L;
+  const double prior = h->Fm[(size_t)out * L + out], noise = h->Sm[(size_t)out * L + out];
   const int64_t Np = h->Np;
   if ((rc = rc_ensure_pred(h))) return rc;
-  std::vector<double> hv(PRED_CAP);
+  std::vector<double> hv(PRED_CAP), hm(PRED_CAP);
   for (int64_t o0 = 0; o0 < n; o0 += PRED_CAP) {
     const int64_t nc = (n - o0 < PRED_CAP) ? n - o0 : PRED_CAP;
     const int64_t ncp = ((nc + 127) / 128) * 128;
     if ((rc = upload_padded(h, h->Xs, Xnew + o0 * M, nc, ncp, M))) return rc;
-    if ((rc = rc_launch_scale_rows(h, h->Xs, h->Zs, h->sqs, ncp))) return rc;
-    if ((rc = rc_launch_cross_gram(h, nc, ncp))) return rc;
+    if ((rc = rc_launch_scale_rows(h, h->Xs, h->Zs, h->sqs, ncp, out))) return rc;
+    if ((rc = rc_launch_cross_gram(h, nc, ncp, out))) return rc;
     {
       RcProfScope ps(h, RC_K_MISC, 0.0);
       hipLaunchKernelGGL(k_rowdot, dim3((unsigned)nc), dim3(256), 0, h->stream, h->KsT, Np, h->alpha, Np, h->pmean);
       RC_HIP(hipGetLastError());
     }
     if ((rc = rc_launch_predict_var(h, ncp))) return rc;
-    RC_HIP(hipMemcpyAsync(mean + o0, h->pmean, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RC_HIP(hipMemcpyAsync(hm.data(), h->pmean, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     RC_HIP(hipMemcpyAsync(hv.data(), h->pvar, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     RC_HIP(hipStreamSynchronize(h->stream));
     for (int64_t i = 0; i < nc; ++i) {
-      double v = h->var - hv[i];                       // k** - |L^-1 k*|^2  (GPflow base_conditional)
-      if (include_noise) v += h->noise;                // predict_y adds the likelihood variance
-      sd[o0 + i] = sqrt(v);                            // SD, not variance (gpr/models.py:384)
+      double v = prior - hv[i];                        // k** - |L^-1 k*|^2  (GPflow base_conditional)
+      if (include_noise) v += noise;                   // predict_y adds the likelihood variance (its diagonal: gpf/likelihoods.py:83)
+      mean[(o0 + i) * L + out] = hm[i];
+      sd[(o0 + i) * L + out] = sqrt(v);                // SD, not variance (gpr/models.py:384)
     }
   }
   return 0;
+}
+
+RC_API int rcgp_predict_mo(rcgp_handle h, int64_t n, const double* Xnew, int include_noise, double* mean, double* sd) {
+  RC_CHECK_H(h);
+  if (n < 0 || (n > 0 && (!Xnew || !mean || !sd))) { h->err = "rcgp_predict: bad argument"; return -2; }
+  int rc;
+  if ((rc = rcgp_factor(h))) return rc;
+  for (int out = 0; out < h->L; ++out)
+    if ((rc = predict_output(h, n, Xnew, include_noise, out, mean, sd))) return rc;
+  return 0;
+}
+
+RC_API int rcgp_predict(rcgp_handle h, int64_t n, const double* Xnew, int include_noise, double* mean, double* sd) {
+  RC_CHECK_H(h);
+  RC_SINGLE_OUTPUT(h, "rcgp_predict");
+  return rcgp_predict_mo(h, n, Xnew, include_noise, mean, sd);
 }
 
 // D[(o*M + m)][n] = d k(X_n, x_o) / d x_om = -(x_om - X_nm) / ell_m^2 * k(X_n, x_o)   (zero on the padding)
@@ -417,6 +516,7 @@ __global__ void k_dkernel_rows(const double* __restrict__ Zs, const double* __re
 
 RC_API int rcgp_predict_gradient(rcgp_handle h, int64_t n, const double* Xnew, double* mean, double* cov) {
   RC_CHECK_H(h);
+  RC_SINGLE_OUTPUT(h, "rcgp_predict_gradient");
   const int M = h->M;
   if (n < 1 || !Xnew || !mean || !cov) { h->err = "rcgp_predict_gradient: bad argument"; return -2; }
   const int64_t rows = n * M, rows_padded = ((rows + 127) / 128) * 128;
@@ -453,6 +553,7 @@ RC_API int rcgp_predict_gradient(rcgp_handle h, int64_t n, const double* Xnew, d
 
 RC_API int rcgp_sobol_closed(rcgp_handle h, int n_slices, const int32_t* slices, double* V) {
   RC_CHECK_H(h);
+  RC_SINGLE_OUTPUT(h, "rcgp_sobol_closed");
   if (n_slices < 0 || (n_slices > 0 && (!slices || !V))) { h->err = "rcgp_sobol_closed: bad argument"; return -2; }
   int rc;
   if ((rc = rcgp_factor(h))) return rc;
@@ -462,6 +563,7 @@ RC_API int rcgp_sobol_closed(rcgp_handle h, int n_slices, const int32_t* slices,
 RC_API int rcgp_sobol_cross(rcgp_handle h, const double* ell_j, double var_j, const double* alpha_j, int n_slices, const int32_t* slices,
                             double* V) {
   RC_CHECK_H(h);
+  RC_SINGLE_OUTPUT(h, "rcgp_sobol_cross");
   if (!ell_j || !alpha_j || n_slices < 0 || (n_slices > 0 && (!slices || !V))) { h->err = "rcgp_sobol_cross: bad argument"; return -2; }
   for (int m = 0; m < h->M; ++m)
     if (!(ell_j[m] > 0.0)) { h->err = "rcgp_sobol_cross: lengthscales must be positive"; return -2; }
@@ -473,6 +575,7 @@ RC_API int rcgp_sobol_cross(rcgp_handle h, const double* ell_j, double var_j, co
 RC_API int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var_a, const double* alpha_a, int n_slices,
                                   const int32_t* slices, double* phi_d, double* psi_d, double* phi_m, double* psi_m) {
   RC_CHECK_H(h);
+  RC_SINGLE_OUTPUT(h, "rcgp_sobol_error_terms");
   if (n_slices < 0 || (n_slices > 0 && (!slices || !phi_d || !psi_d || !phi_m || !psi_m)) || ((ell_a == nullptr) != (alpha_a == nullptr))) {
     h->err = "rcgp_sobol_error_terms: bad argument";
     return -2;
@@ -483,6 +586,32 @@ RC_API int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var
   int rc;
   if ((rc = rcgp_factor(h))) return rc;
   return rc_sobol_error_terms(h, ell_a, var_a, alpha_a, n_slices, slices, phi_d, psi_d, phi_m, psi_m);
+}
+
+static int check_phi(rcgp_handle_s* h, const double* phi, const char* who) {
+  for (int m = 0; m < h->M; ++m)
+    if (!(phi[m] > 0.0) || !(phi[m] < 1.0)) { h->err = std::string(who) + ": phi must lie in (0, 1)"; return -2; }
+  return 0;
+}
+
+RC_API int rcgp_sobol_weight_sum(rcgp_handle h, const double* phi, double pre, const double* alpha, double* sum) {
+  RC_CHECK_H(h);
+  if (!phi || !alpha || !sum) { h->err = "rcgp_sobol_weight_sum: bad argument"; return -2; }
+  int rc;
+  if ((rc = check_phi(h, phi, "rcgp_sobol_weight_sum"))) return rc;
+  return rc_sobol_weight_sum(h, phi, pre, alpha, sum);
+}
+
+RC_API int rcgp_sobol_pair(rcgp_handle h, const double* phi_a, double pre_a, const double* alpha_a, double shift_a, const double* phi_b,
+                           double pre_b, const double* alpha_b, double shift_b, int n_slices, const int32_t* slices, double* V) {
+  RC_CHECK_H(h);
+  if (!phi_a || !alpha_a || !phi_b || !alpha_b || n_slices < 0 || (n_slices > 0 && (!slices || !V))) {
+    h->err = "rcgp_sobol_pair: bad argument";
+    return -2;
+  }
+  int rc;
+  if ((rc = check_phi(h, phi_a, "rcgp_sobol_pair")) || (rc = check_phi(h, phi_b, "rcgp_sobol_pair"))) return rc;
+  return rc_sobol_pair(h, phi_a, pre_a, alpha_a, shift_a, phi_b, pre_b, alpha_b, shift_b, n_slices, slices, V);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

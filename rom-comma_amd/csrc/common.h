@@ -10,6 +10,7 @@
 #define RC_TILE 128            // edge of a workgroup tile and of a diagonal Cholesky block
 #define RC_BK 16               // k-depth of one LDS stage of the MFMA GEMM
 #define RC_MAX_M 64            // largest input dimensionality supported by the fused kernels
+#define RC_MAX_L 16            // most outputs of one covariant GP
 #define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -60,17 +61,20 @@ struct rcgp_handle_s {
   int chain_ext = 4;                 // 128-blocks past its own panel that a chain step keeps up to date (RCGP_EXT >= 1)
   bool diag_attr_set = false;
   int diag_variant = 2;              // 2 = MFMA 16-blocked kernel (k_diag2), 1 = register column sweep (k_diag)
-  int64_t N = 0, Np = 0;       // rows, rows padded to a multiple of RC_TILE
+  int64_t N = 0, Np = 0;       // training rows per output; rows of the whole system, L * Nb
+  int64_t Nb = 0;              // N padded to a multiple of RC_TILE: rows of one output block (Nb == Np when L == 1)
+  int L = 1;                   // outputs modelled jointly (covariant GP, rcgp_create_mo): system row a = l * Nb + n
   int M = 0;
   // hyper-parameters (constrained space)
-  std::vector<double> ell;
+  std::vector<double> ell;     // L x M
+  std::vector<double> Fm, Sm;  // L x L kernel variance and likelihood variance; var == Fm[0], noise == Sm[0] when L == 1
   double var = 1.0, noise = 0.0;
   bool hyper_set = false;
   // state flags
   bool factored = false;       // A holds L (lower), w = L^-1 y, logdiag valid
   bool inverted = false;       // Linv holds L^-1, alpha valid
   // device buffers
-  double *X = nullptr;         // Np x M (padded rows are 0)
+  double *X = nullptr;         // Np x M (padded rows are 0; with L > 1 the N x M inputs repeated once per output block)
   double *Z = nullptr;         // Np x M, X / ell
   double *sq = nullptr;        // Np, -0.5 |z_i|^2
   double *y = nullptr;         // Np (padded 0): pristine targets
@@ -85,7 +89,8 @@ struct rcgp_handle_s {
   size_t partial_elems = 0;
   double *scal = nullptr;      // small device scalars/vectors for results
   int *info = nullptr;         // device: 0 ok, k>0 = leading minor k not positive definite
-  double *ell_d = nullptr;     // device copy of ell (M)
+  double *ell_d = nullptr;     // device copy of ell (L x M)
+  double *FS_d = nullptr;      // device copies of Fm then Sm (2 x L x L)
   // predict scratch
   double *Xs = nullptr, *Zs = nullptr, *sqs = nullptr, *KsT = nullptr, *pmean = nullptr, *pvar = nullptr;
   int64_t pred_cap = 0;
@@ -162,9 +167,9 @@ struct RcProfScope {
 
 // ---- gram.hip
 int rc_launch_scale(rcgp_handle_s* h);                       // Z = X/ell, sq = -0.5|z|^2
-int rc_launch_scale_rows(rcgp_handle_s* h, const double* X, double* Z, double* sq, int64_t rows);
+int rc_launch_scale_rows(rcgp_handle_s* h, const double* X, double* Z, double* sq, int64_t rows, int out = 0);   // new points, lengthscales of output `out`
 int rc_launch_gram(rcgp_handle_s* h);                        // A lower tiles = var*exp(.) (+noise on diag; identity on padding)
-int rc_launch_cross_gram(rcgp_handle_s* h, int64_t n, int64_t np);   // KsT (np x Np) from Zs, Z
+int rc_launch_cross_gram(rcgp_handle_s* h, int64_t n, int64_t np, int out = 0);   // KsT (np x Np) from Zs, Z: n points of output `out`
 
 // ---- gemm.hip (all matrices row-major, dims multiples of 128)
 // C[i][j] -= sum_k P[i][k] P[j][k]   lower tiles of an n x n matrix, K = kk
@@ -185,6 +190,7 @@ int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti
 int rc_launch_trtri_X(rcgp_handle_s* h, int64_t s, int pair0, int npairs);
 // K^-1 tiles fused with the LML-gradient reduction; partial sums -> h->partial ; returns number of partial rows via *nrows
 int rc_launch_grad(rcgp_handle_s* h, int* nrows);
+int rc_launch_grad_mo(rcgp_handle_s* h, int* nrows);     // covariant GP: 2M + 2 sums per lower tile
 // predict: colsum((Linv * Ks)^2) for np test points -> h->pvar (np)
 int rc_launch_predict_var(rcgp_handle_s* h, int64_t np);
 
@@ -201,7 +207,11 @@ int rc_trtri_advance(rcgp_handle_s* h, int64_t done_rows);   // launch (on h->la
 int rc_trtri(rcgp_handle_s* h);                              // Linv = L^-1 (whatever the incremental schedule has not issued yet)
 int rc_alpha(rcgp_handle_s* h);                              // alpha = Linv^T w
 int rc_lml_value(rcgp_handle_s* h, double* lml);             // from logdiag and w
+int rc_sobol_weight_sum(rcgp_handle_s* h, const double* phi, double pre, const double* alpha_host, double* sum);
+int rc_sobol_pair(rcgp_handle_s* h, const double* phi_a, double pre_a, const double* alpha_a, double shift_a, const double* phi_b,
+                  double pre_b, const double* alpha_b, double shift_b, int n_slices, const int32_t* slices, double* V_host);
 int rc_grad_finish(rcgp_handle_s* h, int nrows, double* grad);
+int rc_grad_finish_mo(rcgp_handle_s* h, double* g_ell, double* g_F, double* g_S);
 
 // ---- sobol.hip
 int rc_sobol(rcgp_handle_s* h, const double* ell_j, double var_j, const double* alpha_j_host, int n_slices, const int32_t* slices,

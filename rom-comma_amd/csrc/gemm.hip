@@ -661,6 +661,140 @@ int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same fused K^-1 + gradient reduction for a covariant GP of L outputs (gpf/kernels.py, gpf/likelihoods.py; the
+// reference differentiates by TF autodiff, gpr/models.py:359-361). System row a = (output block, sample); tiles never
+// straddle blocks (every block is padded to a multiple of 128 rows). With W = alpha alpha^T - K^-1, E the unit-variance
+// kernel, K = F_lj E, u_a = x_n / ell_l and d = u_a - u_b, each lower tile of block pair (bi, bj) yields 2M + 2 sums over its
+// valid elements, weighted 2 off the system diagonal (the mirrored element lives in the upper triangle):
+//   [m]       bi == bj: sum W K d_m^2        bi != bj: sum W K d_m u_am     (goes to ell[bi][m])
+//   [M + m]   bi == bj: 0                    bi != bj: sum W K d_m u_bm     (goes to ell[bj][m], negated)
+//   [2M]      sum W E                        (d LML / d F)
+//   [2M + 1]  sum W over the elements with equal in-block index   (d LML / d Sigma)
+// rc_grad_finish_mo adds the tiles of every block pair and applies the factors.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int LZ, int WN>
+__global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t ld, int64_t Np, int64_t N, int M,
+                                        const double* __restrict__ Z, const double* __restrict__ sq, const double* __restrict__ alpha,
+                                        const double* __restrict__ FS, int L, int tb, double* __restrict__ partial) {
+  constexpr int ZL = 2 * 128 * LZ;
+  constexpr int NW = 2 * WN;
+  constexpr int RW = 2 * RC_MAX_M + 2;
+  __shared__ double lds[(GEMM_LDS > ZL ? GEMM_LDS : ZL) + NW * RW];
+  int ti, tj;
+  tri_decode(blockIdx.x, ti, tj);
+  v4d acc[4][Geo<WN>::NI];
+  acc_zero(acc);
+  gemm_mainloop<false, false, WN>(Linv, ld, (int64_t)ti * 128, Linv, ld, (int64_t)tj * 128, (int64_t)ti * 128, Np, acc, lds);
+  RC_LANE_VARS(WN)
+  double* zi = lds;
+  double* zj = lds + 128 * LZ;
+  double* red = lds + (GEMM_LDS > ZL ? GEMM_LDS : ZL);
+  for (int e = threadIdx.x; e < 128 * M; e += 128 * WN) {
+    const int rr = e / M, m = e - rr * M;
+    zi[rr * LZ + m] = Z[((int64_t)ti * 128 + rr) * M + m];
+    zj[rr * LZ + m] = Z[((int64_t)tj * 128 + rr) * M + m];
+  }
+  __syncthreads();
+  const int bi = ti / tb, bj = tj / tb;
+  const bool same = (bi == bj);
+  const double var = FS[bi * L + bj];
+  const int64_t ioff = (int64_t)bi * tb * 128, joff = (int64_t)bj * tb * 128;
+  double ge = 0.0, gdiag = 0.0;
+  double aj[NI_], sj[NI_];
+#pragma unroll
+  for (int ni = 0; ni < NI_; ++ni) {
+    const int64_t j = (int64_t)tj * 128 + wc_ + 16 * ni + fr_;
+    aj[ni] = alpha[j];
+    sj[ni] = sq[j];
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr_ + 16 * mi + 4 * r + fq_;
+      const int64_t i = (int64_t)ti * 128 + row;
+      const double ai = alpha[i], si = sq[i];
+#pragma unroll
+      for (int ni = 0; ni < NI_; ++ni) {
+        const int col = wc_ + 16 * ni + fr_;
+        const int64_t j = (int64_t)tj * 128 + col;
+        double dot = 0.0;
+        for (int m = 0; m < M; ++m) dot = fma(zi[row * LZ + m], zj[col * LZ + m], dot);
+        const double eij = rc_exp(si + sj[ni] + dot);
+        const double wij = ai * aj[ni] - acc[mi][ni][r];
+        const int64_t ii = i - ioff, jj = j - joff;
+        const bool valid = (ii < N) && (jj < N) && (j <= i);
+        const double wgt = valid ? (j == i ? 1.0 : 2.0) : 0.0;
+        const double we = wgt * wij * eij;
+        acc[mi][ni][r] = var * we;
+        ge += we;
+        if (ii == jj) gdiag += wgt * wij;
+      }
+    }
+  auto wave_sum = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  for (int m = 0; m < M; ++m) {
+    double ga = 0.0, gb = 0.0;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double zim = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
+#pragma unroll
+        for (int ni = 0; ni < NI_; ++ni) {
+          const double zjm = zj[(wc_ + 16 * ni + fr_) * LZ + m];
+          const double d = zim - zjm;
+          const double wd = acc[mi][ni][r] * d;
+          ga = fma(wd, same ? d : zim, ga);
+          gb = fma(wd, same ? 0.0 : zjm, gb);
+        }
+      }
+    ga = wave_sum(ga);
+    gb = wave_sum(gb);
+    if (lane_ == 0) {
+      red[wave_ * RW + m] = ga;
+      red[wave_ * RW + M + m] = gb;
+    }
+  }
+  ge = wave_sum(ge);
+  gdiag = wave_sum(gdiag);
+  if (lane_ == 0) {
+    red[wave_ * RW + 2 * M] = ge;
+    red[wave_ * RW + 2 * M + 1] = gdiag;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * M + 2) {
+    const int m = threadIdx.x;
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * RW + m];
+    partial[(int64_t)blockIdx.x * (2 * M + 2) + m] = s;
+  }
+}
+
+int rc_launch_grad_mo(rcgp_handle_s* h, int* nrows) {
+  const int64_t T = h->Np / 128;
+  const int64_t nb = T * (T + 1) / 2;
+  int rc = rc_ensure_partial(h, (size_t)nb * (2 * h->M + 2) + (size_t)(h->L * (h->L + 1) / 2) * (2 * h->M + 2));
+  if (rc) return rc;
+  const double np = (double)h->Np;
+  const int tb = (int)(h->Nb / 128);
+  RcProfScope ps(h, RC_K_GRAD, np * np * np / 3.0);
+  if (h->M <= 32)
+    hipLaunchKernelGGL((k_grad_mo<33, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
+                       h->sq, h->alpha, h->FS_d, h->L, tb, h->partial);
+  else
+    hipLaunchKernelGGL((k_grad_mo<65, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
+                       h->sq, h->alpha, h->FS_d, h->L, tb, h->partial);
+  RC_HIP(hipGetLastError());
+  *nrows = (int)nb;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Predictive variance term: colsum((L^-1 K*)^2). A = Linv (Np x Np, lower) times KsT^T (KsT is np x Np, one test point
 // per row). The product is never written: each tile is squared and column-summed into partial[ti][j].
 // ---------------------------------------------------------------------------------------------------------------------

@@ -10,27 +10,36 @@
 
 #define ZST 130   // LDS stride (doubles) between consecutive m of a Z panel: even (double2 alignment), bank-shift 4 per m
 
+// rows_per_block: rows sharing one lengthscale vector (the output block of a covariant GP; every row when there is one output)
 __global__ void k_scale(const double* __restrict__ X, const double* __restrict__ ell, double* __restrict__ Z, double* __restrict__ sq,
-                        int64_t rows, int M) {
+                        int64_t rows, int M, int64_t rows_per_block) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
+  const double* el = ell + (i / rows_per_block) * M;
   double s = 0.0;
   for (int m = 0; m < M; ++m) {
-    const double z = X[i * M + m] / ell[m];
+    const double z = X[i * M + m] / el[m];
     Z[i * M + m] = z;
     s = fma(z, z, s);
   }
   sq[i] = -0.5 * s;
 }
 
-int rc_launch_scale_rows(rcgp_handle_s* h, const double* X, double* Z, double* sq, int64_t rows) {
+// rows of new points scaled by the lengthscales of output `out`
+int rc_launch_scale_rows(rcgp_handle_s* h, const double* X, double* Z, double* sq, int64_t rows, int out) {
   RcProfScope ps(h, RC_K_MISC, 0.0);
-  hipLaunchKernelGGL(k_scale, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->launch, X, h->ell_d, Z, sq, rows, h->M);
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->launch, X, h->ell_d + (size_t)out * h->M, Z, sq, rows,
+                     h->M, rows > 0 ? rows : 1);
   RC_HIP(hipGetLastError());
   return 0;
 }
 
-int rc_launch_scale(rcgp_handle_s* h) { return rc_launch_scale_rows(h, h->X, h->Z, h->sq, h->Np); }
+int rc_launch_scale(rcgp_handle_s* h) {
+  RcProfScope ps(h, RC_K_MISC, 0.0);
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)((h->Np + 255) / 256)), dim3(256), 0, h->launch, h->X, h->ell_d, h->Z, h->sq, h->Np, h->M, h->Nb);
+  RC_HIP(hipGetLastError());
+  return 0;
+}
 
 __device__ __forceinline__ void tri_decode_g(int64_t id, int& ti, int& tj) {
   int t = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
@@ -42,12 +51,16 @@ __device__ __forceinline__ void tri_decode_g(int64_t id, int& ti, int& tj) {
 
 // CROSS = false: square Gram, lower tiles, + noise on the diagonal, identity on the padding.
 // CROSS = true : rectangular cross-Gram out[row = test point][col = training point], zero on the padding.
+// Several outputs (covariant GP, gpf/kernels.py:93-104 and gpf/likelihoods.py:61-64): the rows/columns come in L blocks of
+// tb tiles; block pair (bi, bj) has variance FS[bi * L + bj] and, where the in-block indices agree, noise FS[L * L + bi * L + bj];
+// nr_valid / nc_valid count the valid rows of ONE block. The test points of a cross-Gram all belong to output rb.
 // 512 threads per 128x128 tile, 4x8 outputs per thread (rows ty + 32a, column pairs 2tx + 32b): <= 128 registers, so four
 // waves per SIMD are resident and the store phase of one wave overlaps the exp phase of the others.
 template <bool CROSS>
 __global__ void __launch_bounds__(512, 4) k_gram(double* __restrict__ out, int64_t ld, const double* __restrict__ Zr,
                                                  const double* __restrict__ sqr, int64_t nr_valid, const double* __restrict__ Zc,
-                                                 const double* __restrict__ sqc, int64_t nc_valid, int M, double var, double noise) {
+                                                 const double* __restrict__ sqc, int64_t nc_valid, int M,
+                                                 const double* __restrict__ FS, int L, int tb, int rb) {
   extern __shared__ double sm[];
   double* zi = sm;                 // [M][ZST]
   double* zj = sm + M * ZST;       // [M][ZST]
@@ -60,6 +73,9 @@ __global__ void __launch_bounds__(512, 4) k_gram(double* __restrict__ out, int64
   } else {
     tri_decode_g(blockIdx.x, ti, tj);
   }
+  const int bi = CROSS ? rb : ti / tb, bj = tj / tb;
+  const double var = FS[bi * L + bj], noise = CROSS ? 0.0 : FS[L * L + bi * L + bj];
+  const int64_t ioff = CROSS ? 0 : (int64_t)bi * tb * 128, joff = (int64_t)bj * tb * 128;   // first row / column of the block
   const int t = threadIdx.x;
   for (int e = t; e < 128 * M; e += 512) {
     const int rr = e / M, m = e - rr * M;
@@ -102,14 +118,15 @@ __global__ void __launch_bounds__(512, 4) k_gram(double* __restrict__ out, int64
       double2 v;
       v.x = var * rc_exp(sia + sj[col] + acc[a][2 * b]);
       v.y = var * rc_exp(sia + sj[col + 1] + acc[a][2 * b + 1]);
+      const int64_t ii = i - ioff, jj = j - joff;      // in-block indices
       if (CROSS) {
-        if (i >= nr_valid || j >= nc_valid) v.x = 0.0;
-        if (i >= nr_valid || j + 1 >= nc_valid) v.y = 0.0;
+        if (ii >= nr_valid || jj >= nc_valid) v.x = 0.0;
+        if (ii >= nr_valid || jj + 1 >= nc_valid) v.y = 0.0;
       } else {
-        if (i == j) v.x += noise;
-        if (i == j + 1) v.y += noise;
-        if (i >= nr_valid || j >= nc_valid) v.x = (i == j) ? 1.0 : 0.0;
-        if (i >= nr_valid || j + 1 >= nc_valid) v.y = (i == j + 1) ? 1.0 : 0.0;
+        if (ii == jj) v.x += noise;
+        if (ii == jj + 1) v.y += noise;
+        if (ii >= nr_valid || jj >= nc_valid) v.x = (i == j) ? 1.0 : 0.0;
+        if (ii >= nr_valid || jj + 1 >= nc_valid) v.y = (i == j + 1) ? 1.0 : 0.0;
       }
       double* dst = out + i * ld + j;
       __builtin_nontemporal_store(v.x, dst);           // written once, read next by another kernel: keep it out of the way in L2
@@ -124,20 +141,20 @@ int rc_launch_gram(rcgp_handle_s* h) {
   const int64_t T = h->Np / 128;
   const size_t lds = gram_lds_bytes(h->M);
   RC_HIP(hipFuncSetAttribute((const void*)k_gram<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const double N = (double)h->N;
+  const double N = (double)h->N * (double)h->L;
   RcProfScope ps(h, RC_K_GRAM, 8.0 * (N * (N + 1.0) / 2.0 + N * (double)h->M));   // algorithmic bytes
   hipLaunchKernelGGL(k_gram<false>, dim3((unsigned)(T * (T + 1) / 2)), dim3(512), lds, h->launch, h->A, h->Np, h->Z, h->sq, h->N, h->Z,
-                     h->sq, h->N, h->M, h->var, h->noise);
+                     h->sq, h->N, h->M, h->FS_d, h->L, (int)(h->Nb / 128), 0);
   RC_HIP(hipGetLastError());
   return 0;
 }
 
-int rc_launch_cross_gram(rcgp_handle_s* h, int64_t n, int64_t np) {
+int rc_launch_cross_gram(rcgp_handle_s* h, int64_t n, int64_t np, int out) {
   const size_t lds = gram_lds_bytes(h->M);
   RC_HIP(hipFuncSetAttribute((const void*)k_gram<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   RcProfScope ps(h, RC_K_MISC, 0.0);
   hipLaunchKernelGGL(k_gram<true>, dim3((unsigned)(h->Np / 128), (unsigned)(np / 128)), dim3(512), lds, h->launch, h->KsT, h->Np, h->Zs,
-                     h->sqs, n, h->Z, h->sq, h->N, h->M, h->var, 0.0);
+                     h->sqs, n, h->Z, h->sq, h->N, h->M, h->FS_d, h->L, (int)(h->Nb / 128), out);
   RC_HIP(hipGetLastError());
   return 0;
 }

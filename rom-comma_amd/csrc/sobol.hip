@@ -239,38 +239,14 @@ static int sobol_make_g(rcgp_handle_s* h, const double* ell, double var, const d
   return 0;
 }
 
-int rc_sobol(rcgp_handle_s* h, const double* ell_j, double var_j, const double* alpha_j_host, int n_slices, const int32_t* slices,
-             double* V_host) {
+// The pair quadratic forms V[s] = sum_{n,n'} g_l[n] g_j[n'] prod_{m in slice s} h_m(n,n') for weight vectors already on the device
+// (Np_x rows, zero beyond the N valid ones) with their phi vectors on the host. sym: g_j is g_l, only the lower pair tiles run.
+static int sobol_run_slices(rcgp_handle_s* h, int64_t Np, const double* g_l, const double* g_j, const std::vector<double>& phi_l,
+                            const std::vector<double>& phi_j, bool sym, double empty_value, double* consts_d, double* out_d, int n_slices,
+                            const int32_t* slices, double* V_host) {
   const int M = h->M;
-  const int64_t Np = h->Np, T = Np / 128;
-  const bool sym = (ell_j == nullptr);
-  // scratch layout in h->sob: g_l[Np] g_j[Np] alpha_j[Np] phi_l[M] phi_j[M] consts[4M] sums[4] out[3M]
-  const size_t need = (size_t)3 * Np + 2 * M + 4 * M + 4 + 3 * M;
-  if (h->sob_elems < need) {
-    if (h->sob) { RC_HIP(hipStreamSynchronize(h->stream)); RC_HIP(hipFree(h->sob)); h->sob = nullptr; }
-    RC_HIP(hipMalloc(&h->sob, need * sizeof(double)));
-    h->sob_elems = need;
-  }
-  double* g_l = h->sob;
-  double* g_j = g_l + Np;
-  double* a_j = g_j + Np;
-  double* phi_l_d = a_j + Np;
-  double* phi_j_d = phi_l_d + M;
-  double* consts_d = phi_j_d + M;
-  double* sums_d = consts_d + 4 * M;
-  double* out_d = sums_d + 4;
-  std::vector<double> phi_l, phi_j;
-  int rc = sobol_make_g(h, h->ell.data(), h->var, h->alpha, phi_l_d, g_l, sums_d, phi_l);
-  if (rc) return rc;
-  if (!sym) {
-    RC_HIP(hipMemsetAsync(a_j, 0, (size_t)Np * sizeof(double), h->stream));
-    RC_HIP(hipMemcpyAsync(a_j, alpha_j_host, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    rc = sobol_make_g(h, ell_j, var_j, a_j, phi_j_d, g_j, sums_d + 2, phi_j);
-    if (rc) return rc;
-  } else {
-    phi_j = phi_l;
-    g_j = g_l;
-  }
+  const int64_t T = Np / 128;
+  int rc;
   std::vector<double> consts(4 * M);
   for (int m = 0; m < M; ++m) {
     const double a = phi_l[m] * phi_j[m];
@@ -281,9 +257,6 @@ int rc_sobol(rcgp_handle_s* h, const double* ell_j, double var_j, const double* 
   }
   RC_HIP(hipMemcpyAsync(consts_d, consts.data(), (size_t)4 * M * sizeof(double), hipMemcpyHostToDevice, h->stream));
   RC_HIP(hipStreamSynchronize(h->stream));
-  double sums[4];
-  RC_HIP(hipMemcpy(sums, sums_d, 4 * sizeof(double), hipMemcpyDeviceToHost));
-  const double empty_value = sym ? sums[1] * sums[1] : sums[1] * sums[3];
 
   const int64_t nblk = sym ? T * (T + 1) / 2 : T * T;
   rc = rc_ensure_partial(h, (size_t)nblk * 3 * M);
@@ -337,6 +310,115 @@ int rc_sobol(rcgp_handle_s* h, const double* ell_j, double var_j, const double* 
     }
   }
   return 0;
+}
+
+// scratch layout in h->sob: g_l[Np] g_j[Np] alpha_j[Np] phi_l[M] phi_j[M] consts[4M] sums[4] out[3M]
+static int sobol_scratch(rcgp_handle_s* h, int64_t Np) {
+  const int M = h->M;
+  const size_t need = (size_t)3 * Np + 2 * M + 4 * M + 4 + 3 * M;
+  if (h->sob_elems < need) {
+    if (h->sob) { RC_HIP(hipStreamSynchronize(h->stream)); RC_HIP(hipFree(h->sob)); h->sob = nullptr; }
+    RC_HIP(hipMalloc(&h->sob, need * sizeof(double)));
+    h->sob_elems = need;
+  }
+  return 0;
+}
+
+int rc_sobol(rcgp_handle_s* h, const double* ell_j, double var_j, const double* alpha_j_host, int n_slices, const int32_t* slices,
+             double* V_host) {
+  const int M = h->M;
+  const int64_t Np = h->Np;
+  const bool sym = (ell_j == nullptr);
+  int rc = sobol_scratch(h, Np);
+  if (rc) return rc;
+  double* g_l = h->sob;
+  double* g_j = g_l + Np;
+  double* a_j = g_j + Np;
+  double* phi_l_d = a_j + Np;
+  double* phi_j_d = phi_l_d + M;
+  double* consts_d = phi_j_d + M;
+  double* sums_d = consts_d + 4 * M;
+  double* out_d = sums_d + 4;
+  std::vector<double> phi_l, phi_j;
+  rc = sobol_make_g(h, h->ell.data(), h->var, h->alpha, phi_l_d, g_l, sums_d, phi_l);
+  if (rc) return rc;
+  if (!sym) {
+    RC_HIP(hipMemsetAsync(a_j, 0, (size_t)Np * sizeof(double), h->stream));
+    RC_HIP(hipMemcpyAsync(a_j, alpha_j_host, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = sobol_make_g(h, ell_j, var_j, a_j, phi_j_d, g_j, sums_d + 2, phi_j);
+    if (rc) return rc;
+  } else {
+    phi_j = phi_l;
+    g_j = g_l;
+  }
+  RC_HIP(hipStreamSynchronize(h->stream));
+  double sums[4];
+  RC_HIP(hipMemcpy(sums, sums_d, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  const double empty_value = sym ? sums[1] * sums[1] : sums[1] * sums[3];
+  return sobol_run_slices(h, Np, g_l, g_j, phi_l, phi_j, sym, empty_value, consts_d, out_d, n_slices, slices, V_host);
+}
+
+// g[n] -= shift on the valid rows
+__global__ void k_sobol_shift(double* __restrict__ g, int64_t N, double shift) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) g[i] -= shift;
+}
+
+// Weight vector of one "virtual output" (phi, pre, alpha) on the device: g[n] = pre exp(-1/2 sum_m phi_m x_nm^2) alpha[n] - shift;
+// sums_d[0] = sum of g before the shift, sums_d[1] = after. The covariant Sobol calculation (gsa/calibrators.py:82-92 with a
+// non-diagonal F) builds its (l, J) weight vectors this way: phi = 1/(ell_l ell_J + 1), pre = F_lJ sqrt(prod ell_l ell_J phi),
+// alpha = K_inv_Y[J], shift = the mean over (J, N) for that l.
+static int sobol_make_weights(rcgp_handle_s* h, int64_t Np, const double* phi, double pre, const double* alpha_host, double shift,
+                              double* stage_d, double* phi_d, double* g_d, double* sums_d) {
+  const int M = h->M;
+  RC_HIP(hipMemsetAsync(stage_d, 0, (size_t)Np * sizeof(double), h->stream));
+  RC_HIP(hipMemcpyAsync(stage_d, alpha_host, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RC_HIP(hipMemcpyAsync(phi_d, phi, (size_t)M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RcProfScope ps(h, RC_K_MISC, 0.0);
+  const unsigned nb = (unsigned)((Np + 255) / 256);
+  hipLaunchKernelGGL(k_sobol_g0, dim3(nb), dim3(256), 0, h->stream, h->X, stage_d, phi_d, pre, h->N, Np, M, g_d, (double*)nullptr);
+  hipLaunchKernelGGL(k_sum1, dim3(1), dim3(1024), 0, h->stream, g_d, h->N, sums_d);
+  hipLaunchKernelGGL(k_sobol_shift, dim3(nb), dim3(256), 0, h->stream, g_d, h->N, shift);
+  hipLaunchKernelGGL(k_sum1, dim3(1), dim3(1024), 0, h->stream, g_d, h->N, sums_d + 1);
+  RC_HIP(hipGetLastError());
+  RC_HIP(hipStreamSynchronize(h->stream));                 // alpha_host and phi may be reused by the caller
+  return 0;
+}
+
+int rc_sobol_weight_sum(rcgp_handle_s* h, const double* phi, double pre, const double* alpha_host, double* sum) {
+  const int M = h->M;
+  const int64_t Np = h->Nb;                                // rows of one output block: X's first block is the N x M design matrix
+  int rc = sobol_scratch(h, Np);
+  if (rc) return rc;
+  double* g_l = h->sob;
+  double* a_j = g_l + 2 * Np;
+  double* phi_l_d = a_j + Np;
+  double* sums_d = phi_l_d + 2 * M + 4 * M;
+  if ((rc = sobol_make_weights(h, Np, phi, pre, alpha_host, 0.0, a_j, phi_l_d, g_l, sums_d))) return rc;
+  RC_HIP(hipMemcpy(sum, sums_d, sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int rc_sobol_pair(rcgp_handle_s* h, const double* phi_a, double pre_a, const double* alpha_a, double shift_a, const double* phi_b,
+                  double pre_b, const double* alpha_b, double shift_b, int n_slices, const int32_t* slices, double* V_host) {
+  const int M = h->M;
+  const int64_t Np = h->Nb;
+  int rc = sobol_scratch(h, Np);
+  if (rc) return rc;
+  double* g_l = h->sob;
+  double* g_j = g_l + Np;
+  double* a_j = g_j + Np;
+  double* phi_l_d = a_j + Np;
+  double* phi_j_d = phi_l_d + M;
+  double* consts_d = phi_j_d + M;
+  double* sums_d = consts_d + 4 * M;
+  double* out_d = sums_d + 4;
+  if ((rc = sobol_make_weights(h, Np, phi_a, pre_a, alpha_a, shift_a, a_j, phi_l_d, g_l, sums_d))) return rc;
+  if ((rc = sobol_make_weights(h, Np, phi_b, pre_b, alpha_b, shift_b, a_j, phi_j_d, g_j, sums_d + 2))) return rc;
+  double sums[4];
+  RC_HIP(hipMemcpy(sums, sums_d, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  const std::vector<double> pa(phi_a, phi_a + M), pb(phi_b, phi_b + M);
+  return sobol_run_slices(h, Np, g_l, g_j, pa, pb, false, sums[1] * sums[3], consts_d, out_d, n_slices, slices, V_host);
 }
 
 // =====================================================================================================================

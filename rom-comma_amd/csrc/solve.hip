@@ -170,7 +170,7 @@ int rc_lml_value(rcgp_handle_s* h, double* lml) {
     h->factored = false;
     return info;
   }
-  *lml = -0.5 * host[0] - host[1] - 0.5 * (double)h->N * 1.8378770664093454836;   // log(2 pi)
+  *lml = -0.5 * host[0] - host[1] - 0.5 * (double)(h->N * h->L) * 1.8378770664093454836;   // log(2 pi)
   return 0;
 }
 
@@ -203,4 +203,61 @@ int rc_grad_finish(rcgp_handle_s* h, int nrows, double* grad) {
   grad[M] = 0.5 * host[M] / h->var;
   grad[M + 1] = 0.5 * host[M + 1];
   return 0;
+}
+
+// Covariant GP: out[p][c] = sum over the lower tiles of block pair p = (bi, bj), bj <= bi, of partial[tile][c]
+// (tile (ti, tj) is row ti (ti + 1) / 2 + tj of partial); one workgroup per (c, p), fixed-order tree.
+__global__ void __launch_bounds__(256) k_reduce_pairs(const double* __restrict__ partial, int tb, int cols, double* __restrict__ out) {
+  __shared__ double sm[256];
+  const int c = blockIdx.x, p = blockIdx.y;
+  int bi = 0, rem = p;
+  while (rem > bi) { rem -= bi + 1; ++bi; }
+  const int bj = rem;
+  double s = 0.0;
+  for (int e = threadIdx.x; e < tb * tb; e += 256) {
+    const int64_t ti = (int64_t)bi * tb + e / tb, tj = (int64_t)bj * tb + e % tb;
+    if (tj <= ti) s += partial[(ti * (ti + 1) / 2 + tj) * cols + c];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(int64_t)p * cols + c] = sm[0];
+}
+
+// Partial derivatives of the LML with every entry of ell (L x M), F (L x L) and Sigma (L x L) treated as independent
+// (k_grad_mo explains the per-tile sums and their weights).
+int rc_grad_finish_mo(rcgp_handle_s* h, double* g_ell, double* g_F, double* g_S) {
+  const int M = h->M, L = h->L, cols = 2 * M + 2, npairs = L * (L + 1) / 2;
+  const int tb = (int)(h->Nb / 128);
+  const int64_t T = h->Np / 128;
+  double* out_d = h->partial + (size_t)(T * (T + 1) / 2) * cols;          // behind the per-tile rows
+  int rc = 0;
+  if (h->partial_elems < (size_t)(T * (T + 1) / 2) * cols + (size_t)npairs * cols) { h->err = "rc_grad_finish_mo: scratch too small"; return -7; }
+  {
+    RcProfScope ps(h, RC_K_MISC, 0.0);
+    hipLaunchKernelGGL(k_reduce_pairs, dim3((unsigned)cols, (unsigned)npairs), dim3(256), 0, h->stream, h->partial, tb, cols, out_d);
+    RC_HIP(hipGetLastError());
+  }
+  std::vector<double> host((size_t)npairs * cols);
+  RC_HIP(hipMemcpyAsync(host.data(), out_d, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  std::vector<double> R((size_t)L * M, 0.0);
+  int p = 0;
+  for (int bi = 0; bi < L; ++bi)
+    for (int bj = 0; bj <= bi; ++bj, ++p) {
+      const double* o = host.data() + (size_t)p * cols;
+      for (int m = 0; m < M; ++m) {
+        R[(size_t)bi * M + m] += o[m];
+        if (bi != bj) R[(size_t)bj * M + m] -= o[M + m];
+      }
+      const double f = (bi == bj) ? 0.5 : 0.25;                           // 1/2 tr(W dK); an off-diagonal pair sum holds both mirrored blocks
+      g_F[bi * L + bj] = g_F[bj * L + bi] = f * o[2 * M];
+      g_S[bi * L + bj] = g_S[bj * L + bi] = f * o[2 * M + 1];
+    }
+  for (int l = 0; l < L; ++l)
+    for (int m = 0; m < M; ++m) g_ell[l * M + m] = 0.5 * R[(size_t)l * M + m] / h->ell[(size_t)l * M + m];
+  return rc;
 }

@@ -1,7 +1,8 @@
 """Kernel parameter store (reference gpr/kernels.py:30-180). A Kernel is a Model whose Data are the kernel variance,
 (1,L) for independent outputs, and the lengthscales, (L,M) anisotropic or (L,1) isotropic. In the reference
 ``implementation`` builds GPflow kernel objects; here it yields plain per-output parameter records that the HIP-backed GP
-pushes to the device with ``rcgp_set_hyper`` -- the kernel arithmetic itself lives in csrc/gram.hip.
+pushes to the device with ``rcgp_set_hyper`` -- the kernel arithmetic itself lives in csrc/gram.hip. An (L,L) variance is the
+covariant kernel of ``romcomma.gpf.kernels.RBF``: one record for all outputs, pushed with ``rcgp_set_hyper_mo``.
 """
 from __future__ import annotations
 
@@ -104,7 +105,10 @@ class RBF(Kernel):
         lengthscales = self._data.frames.lengthscales.np
         if self._implementation is None:
             if variance.shape[0] != 1:
-                raise NotImplementedError('covariant (L,L) kernel variance: only independent outputs are implemented on this backend')
+                # one multi-output kernel (gpr/kernels.py:179): (L,L) variance, (L,M) or (L,1) lengthscales (gpf/kernels.py:106-127)
+                self._implementation = ({'variance': np.asarray(variance, dtype=float).copy(),
+                                         'lengthscales': np.asarray(lengthscales, dtype=float).copy()},)
+                return self._implementation
             self._implementation = tuple({'variance': max(float(variance[0, l]), self.VARIANCE_FLOOR),
                                           'lengthscales': np.asarray(lengthscales[l], dtype=float).copy()}
                                          for l in range(variance.shape[1]))

@@ -20,7 +20,7 @@ from romcomma_amd.base.classes import Data, Frame, Model
 from romcomma_amd.data.storage import Fold
 from romcomma_amd.data.storage import Frame as DataFrameCSV
 from romcomma_amd.gpr.kernels import Kernel
-from romcomma_amd.gpr.optimize import fit_lbfgsb
+from romcomma_amd.gpr.optimize import fit_lbfgsb, fit_lbfgsb_mo
 
 
 class Likelihood(Model):
@@ -216,11 +216,15 @@ class GPR(Model):
 
 
 class HipGP(GPR):
-    """Independent-output ARD-RBF GPs on one MI355X through librcgp.so.
+    """ARD-RBF GPs on one MI355X through librcgp.so.
 
-    One device handle holds X (shared by the L outputs) and the N x N work matrices; the outputs are fitted / queried in turn
-    (``rcgp_set_y``), exactly as the reference loops ``for gp in self._implementation`` (gpr/models.py:360-361). To spread
-    outputs or folds over GPUs, run one process per GPU and give each its share (``romcomma_amd.user.run``).
+    Independent outputs: one device handle holds X (shared by the L outputs) and the N x N work matrices; the outputs are
+    fitted / queried in turn (``rcgp_set_y``), exactly as the reference loops ``for gp in self._implementation``
+    (gpr/models.py:360-361). To spread outputs or folds over GPUs, run one process per GPU and give each its share
+    (``romcomma_amd.user.run``).
+
+    Covariant outputs (``is_covariant``): one (L N) x (L N) system, the reference's ``romcomma.gpf.models.MOGPR`` behind the
+    covariant branches of gpr/models.py:335-338, 363-367, 377-379, 429-431 -- an ``rcgp_create_mo`` handle.
     """
 
     @classmethod
@@ -230,8 +234,7 @@ class HipGP(GPR):
 
     def __init__(self, name: str, fold: Fold, is_read: bool | None, is_covariant: bool, is_isotropic: bool,
                  kernel_parameters: Kernel.Data | None = None, likelihood_variance: np.ndarray | None = None, device: int | None = None):
-        if is_covariant:
-            raise NotImplementedError('covariant (dependent-output) GPs are outside this backend: independent outputs only')
+        self._is_covariant = bool(is_covariant)
         self._device = device
         self._handle = None
         self._cache: Dict[int, Dict[str, np.ndarray]] = {}
@@ -250,7 +253,10 @@ class HipGP(GPR):
     def handle(self) -> _lib.RcGP:
         """The ``rcgp_handle`` (created on first use; X uploaded once)."""
         if self._handle is None:
-            self._handle = _lib.RcGP(self._X, self._Y[:, 0], device=self.device)
+            if self._is_covariant:
+                self._handle = _lib.RcMOGP(self._X, self._Y, device=self.device)
+            else:
+                self._handle = _lib.RcGP(self._X, self._Y[:, 0], device=self.device)
             self._active_output = 0
         return self._handle
 
@@ -263,6 +269,25 @@ class HipGP(GPR):
         record = self._kernel.implementation[l]
         noise = max(float(self._likelihood.data.frames.variance.np[0, l]), Likelihood.VARIANCE_FLOOR)   # gpr/models.py:341
         return np.broadcast_to(record['lengthscales'], (self._M,)).copy(), record['variance'], noise
+
+    def _hyper_mo(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(lengthscales (L,M), kernel variance (L,L), likelihood variance (L,L)) of the covariant GP as MOGPR.__init__ receives
+        them (gpr/models.py:335-338). The reference then reduces ANY likelihood variance to its diagonal: the shape test at
+        gpf/models.py:121 compares a bound method with a tuple, is always true, and band_part(., 0, 0) follows (:122-123)."""
+        record = self._kernel.implementation[0]
+        lengthscales = np.broadcast_to(np.asarray(record['lengthscales'], dtype=np.float64), (self._L, self._M)).copy()
+        noise = np.broadcast_to(np.asarray(self._likelihood.data.frames.variance.np, dtype=np.float64), (self._L, self._L))
+        return lengthscales, np.asarray(record['variance'], dtype=np.float64), np.diag(np.diag(noise))
+
+    def _select_mo(self) -> _lib.RcMOGP:
+        """The covariant GP with its stored hyper-parameters current on the device."""
+        gp = self.handle
+        lengthscales, variance, noise = self._hyper_mo()
+        signature = ('mo', lengthscales.tobytes(), variance.tobytes(), noise.tobytes())
+        if getattr(self, '_device_signature', None) != signature:
+            gp.set_hyper(lengthscales, (variance + variance.T) / 2, noise)
+            self._device_signature = signature
+        return gp
 
     def _select(self, l: int) -> _lib.RcGP:
         """Make output ``l`` with its stored hyper-parameters current on the device. Re-sending identical values is skipped so
@@ -283,7 +308,7 @@ class HipGP(GPR):
         """One (output index, hyper-parameter record) pair per independent output; the device handle is shared."""
         if self._implementation is None:
             self._cache = {}
-            self._implementation = tuple((l, record) for l, record in enumerate(self._kernel.implementation))
+            self._implementation = tuple((l, record) for l, record in enumerate(self._kernel.implementation))   # one record if covariant
         return self._implementation
 
     # ---- the GPR contract
@@ -305,6 +330,25 @@ class HipGP(GPR):
         meta.update(kwargs)
         meta.pop('result', None)
         gp = self.handle
+        if self._is_covariant:
+            # one optimisation over the Cholesky-parametrised (L,L) variances (gpr/models.py:359-367, gpf/base.py:32-96)
+            lengthscales, variance, noise = self._hyper_mo()
+            self._device_signature = None
+            fit = fit_lbfgsb_mo(gp, lengthscales, variance, noise, is_isotropic=self._is_isotropic,
+                                train_kernel_variance=bool(kernel_options['variance']),
+                                train_kernel_covariance=bool(kernel_options['covariance']),
+                                train_lengthscales=bool(kernel_options['lengthscales']['covariant']),
+                                train_likelihood_variance=bool(likelihood_options['variance']),
+                                train_likelihood_covariance=bool(likelihood_options['covariance']), method=method, **meta)
+            meta.update({'result': str((fit['result'],)), 'kernel': kernel_options, 'likelihood': likelihood_options})
+            self.write_meta(meta)
+            self._likelihood.data.replace(variance=fit['noise'], log_marginal=np.atleast_2d(fit['log_marginal']))
+            n_ell = 1 if self._is_isotropic else self._M
+            self._kernel.data.replace(variance=fit['variance'], lengthscales=fit['lengthscales'][:, :n_ell])
+            self._kernel._implementation = None
+            self._implementation = None
+            self._implementation = self.implementation
+            return meta
         fits = []
         for l in range(self._L):
             lengthscales, variance, noise = self._hyper(l)
@@ -329,12 +373,17 @@ class HipGP(GPR):
         return meta
 
     def log_marginal_likelihood(self) -> np.ndarray:
-        """(L,) log marginal likelihood at the stored hyper-parameters."""
+        """(L,) log marginal likelihood at the stored hyper-parameters ((1,) for a covariant GP: one joint likelihood)."""
+        if self._is_covariant:
+            return np.array([self._select_mo().lml()])
         return np.array([self._select(l).lml() for l, _ in self.implementation])
 
     def predict(self, X: np.ndarray, y_instead_of_f: bool = True) -> Tuple[np.ndarray, np.ndarray]:
         """(mean (o,L), SD (o,L)): predict_y when ``y_instead_of_f`` else predict_f (gpr/models.py:375-384)."""
         X = np.ascontiguousarray(X, dtype=np.float64)
+        if self._is_covariant:                                                 # gpr/models.py:377-379, gpf/models.py:84-113
+            mean, sd = self._select_mo().predict(X, y_instead_of_f)
+            return np.atleast_2d(mean), np.atleast_2d(sd)
         results = [self._select(l).predict(X, y_instead_of_f) for l, _ in self.implementation]
         mean = np.stack([r[0] for r in results], axis=1)
         sd = np.stack([r[1] for r in results], axis=1)
@@ -345,6 +394,8 @@ class HipGP(GPR):
         covariance (o, o, L, M, M). As in the reference: mean = dK^T alpha; cov = -(L^-1 dK)^T (L^-1 dK) with
         k(x_O, x_o) / ell_M^2 added where the two gradient components coincide (M == m); ``y_instead_of_f`` is accepted and,
         exactly as in the reference, has no effect. dK = d k(X, x)/dx is analytic here (tape.jacobian in the reference)."""
+        if self._is_covariant:
+            raise NotImplementedError('predict_gradient of a covariant GP (gpr/models.py:392-405) is not built on this backend')
         x = np.ascontiguousarray(x, dtype=np.float64)
         o = x.shape[0]
         mean = np.empty((o, self._L, self._M))
@@ -364,18 +415,30 @@ class HipGP(GPR):
     @property
     def K_cho(self) -> np.ndarray:
         """(L,N,N) lower Cholesky factors of K_l + noise_l I (gpr/models.py:427-439). Copies N^2 doubles per output to the
-        host: meant for inspection, the accelerated consumers use the device-resident factor."""
+        host: meant for inspection, the accelerated consumers use the device-resident factor. Covariant: (LN, LN) (:429-431)."""
+        if self._is_covariant:
+            return self._select_mo().k_cho()
         return np.stack([self._select(l).k_cho() for l, _ in self.implementation])
 
     @property
     def K_inv_Y(self) -> np.ndarray:
-        """(L,1,N): alpha_l = (K_l + noise_l I)^-1 y_l (gpr/models.py:441-444)."""
+        """(L,1,N): alpha_l = (K_l + noise_l I)^-1 y_l (gpr/models.py:441-444); covariant: the (LN) solve reshaped."""
+        if self._is_covariant:
+            return self._select_mo().k_inv_y()
         return np.stack([self._select(l).k_inv_y() for l, _ in self.implementation])[:, None, :]
 
     def check_K_inv_Y(self, x: np.ndarray) -> np.ndarray:
         """FOR TESTING: RMS over the o rows of k(x,X) . K_inv_Y - predict(x); ~0 (gpr/models.py:446-463)."""
         predicted = self.predict(x)[0]
         alpha = self.K_inv_Y[:, 0, :]
+        if self._is_covariant:                                                 # 'loLN, LiN -> ol' (gpr/models.py:456-457)
+            lengthscales, variance, _ = self._hyper_mo()
+            u = (np.asarray(x)[None, :, :] / lengthscales[:, None, :])                        # (L, o, M)
+            U = (self._X[None, :, :] / lengthscales[:, None, :])                              # (L, N, M)
+            d = u[:, :, None, None, :] - U[None, None, :, :, :]
+            kernel = variance[:, None, :, None] * np.exp(-0.5 * np.einsum('...M,...M->...', d, d))
+            result = np.einsum('loLN,LN->ol', kernel, alpha) - predicted
+            return np.sqrt(np.sum(result * result, axis=0) / predicted.shape[0])
         result = np.empty_like(predicted)
         for l, record in self.implementation:
             z = x / record['lengthscales']

@@ -80,3 +80,96 @@ def fit_lbfgsb(gp, lengthscales, variance: float, noise: float, is_isotropic: bo
     log_marginal = gp.lml()
     return {'lengthscales': np.broadcast_to(ell, (M,)).copy(), 'variance': var, 'noise': nse, 'log_marginal': log_marginal,
             'result': result, 'nfev': state['nfev']}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Covariant (dependent-output) GP: the reference's romcomma.gpf.models.MOGPR behind the same gf.optimizers.Scipy call
+# ---------------------------------------------------------------------------------------------------------------------
+
+CHOLESKY_DIAGONAL_LOWER_BOUND = 1.0e-3        # gpf/base.py:35
+
+
+def variance_to_params(V: np.ndarray):
+    """gpf.base.Variance.__init__ (gpf/base.py:71-96): the (L, L) matrix is held as its Cholesky factor, the diagonal through
+    positive(lower=1e-3) -- returned here unconstrained -- and the strictly lower triangle row by row."""
+    C = np.linalg.cholesky(np.asarray(V, dtype=np.float64))
+    d = np.diag(C)
+    if d.min() <= CHOLESKY_DIAGONAL_LOWER_BOUND:
+        raise ValueError(f'The Cholesky diagonal of a Variance must be strictly greater than {CHOLESKY_DIAGONAL_LOWER_BOUND}.')   # :87-88
+    L = C.shape[0]
+    lower = np.array([C[i, j] for i in range(1, L) for j in range(i)], dtype=np.float64)
+    return inv_softplus(d - CHOLESKY_DIAGONAL_LOWER_BOUND), lower
+
+
+def params_to_cholesky(u_diag: np.ndarray, lower: np.ndarray) -> np.ndarray:
+    """gpf.base.Variance.cholesky (gpf/base.py:42-50)."""
+    L = len(u_diag)
+    C = np.zeros((L, L))
+    k = 0
+    for i in range(1, L):
+        C[i, :i] = lower[k:k + i]
+        k += i
+    C[np.diag_indices(L)] = CHOLESKY_DIAGONAL_LOWER_BOUND + softplus(u_diag)
+    return C
+
+
+def _cholesky_chain(dV: np.ndarray, C: np.ndarray, u_diag: np.ndarray):
+    """d/d(u_diag), d/d(lower) from d/dV taken entry by entry, V = C C^T."""
+    dC = (dV + dV.T) @ C
+    L = C.shape[0]
+    lower = np.array([dC[i, j] for i in range(1, L) for j in range(i)], dtype=np.float64)
+    return np.diag(dC) * sigmoid(u_diag), lower
+
+
+def fit_lbfgsb_mo(gp, lengthscales, F, Sigma, is_isotropic: bool = False, train_kernel_variance: bool = True,
+                  train_kernel_covariance: bool = False, train_lengthscales: bool = False, train_likelihood_variance: bool = True,
+                  train_likelihood_covariance: bool = True, method: str = 'L-BFGS-B', callback=None, **options: Any) -> Dict[str, Any]:
+    """Minimise -LML of a covariant GP (``romcomma_amd._lib.RcMOGP``) over its trainable parameters. The defaults are what
+    Kernel.calibrate and Likelihood.calibrate switch on for a covariant GP (gpr/kernels.py:56-65, gpr/models.py:60,74-76): the
+    Cholesky diagonal of the kernel variance and the whole Cholesky factor of the likelihood variance; the kernel's lower
+    triangle and the lengthscales stay where the independent fit left them.
+
+    Returns dict(lengthscales (L, M), variance (L, L), noise (L, L), log_marginal, result, nfev)."""
+    L, M = gp.L, gp.M
+    n_ell = 1 if is_isotropic else M
+    ell0 = np.broadcast_to(np.asarray(lengthscales, dtype=np.float64).reshape(L, -1)[:, :n_ell], (L, n_ell)).copy()
+    kd, kl = variance_to_params(F)
+    nd, nl = variance_to_params(Sigma)
+    parts = {'kd': kd, 'kl': kl, 'ue': inv_softplus(ell0).reshape(-1), 'nd': nd, 'nl': nl}
+    names = [n for n, on in (('kd', train_kernel_variance), ('kl', train_kernel_covariance), ('ue', train_lengthscales),
+                             ('nd', train_likelihood_variance), ('nl', train_likelihood_covariance)) if on and len(parts[n])]
+    state = {'nfev': 0}
+
+    def unpack(u):
+        p = dict(parts)
+        k = 0
+        for n in names:
+            p[n] = u[k:k + len(parts[n])]
+            k += len(parts[n])
+        return p
+
+    def build(p):
+        Ck, Cn = params_to_cholesky(p['kd'], p['kl']), params_to_cholesky(p['nd'], p['nl'])
+        ell = np.broadcast_to(softplus(p['ue']).reshape(L, n_ell), (L, M))
+        Fm, Sm = Ck @ Ck.T, Cn @ Cn.T
+        return ell, Ck, Cn, (Fm + Fm.T) / 2, (Sm + Sm.T) / 2
+
+    def objective(u):
+        p = unpack(u)
+        ell, Ck, Cn, Fm, Sm = build(p)
+        gp.set_hyper(ell, Fm, Sm)
+        lml, gF, gell, gS = gp.lml_grad()
+        state['nfev'] += 1
+        g = {}
+        g['kd'], g['kl'] = _cholesky_chain(gF, Ck, p['kd'])
+        g['nd'], g['nl'] = _cholesky_chain(gS, Cn, p['nd'])
+        g_ell = gell.sum(axis=1, keepdims=True) if is_isotropic else gell
+        g['ue'] = (g_ell * sigmoid(p['ue'].reshape(L, n_ell))).reshape(-1)
+        return -lml, -np.concatenate([g[n] for n in names])
+
+    opts = {'maxiter': 5000, 'gtol': 1e-16} | options
+    u0 = np.concatenate([parts[n] for n in names]) if names else np.zeros(0)
+    result = scipy.optimize.minimize(objective, u0, jac=True, method=method, options=opts, callback=callback) if names else None
+    ell, Ck, Cn, Fm, Sm = build(unpack(result.x if names else u0))
+    gp.set_hyper(ell, Fm, Sm)
+    return {'lengthscales': np.array(ell), 'variance': Fm, 'noise': Sm, 'log_marginal': gp.lml(), 'result': result, 'nfev': state['nfev']}

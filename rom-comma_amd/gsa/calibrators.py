@@ -11,12 +11,56 @@ from typing import Any, Dict, List, Sequence, Tuple
 
 import numpy as np
 
+from romcomma_amd import _lib
 from romcomma_amd.gpr.models import GPR
 from romcomma_amd.gsa.base import Calibrator
 
 
+def _virtual_outputs(K_inv_Y: np.ndarray, F: np.ndarray, lengthscales: np.ndarray, is_F_diagonal: bool):
+    """The weight-vector recipes behind 'lLN, lLNjJn, jJn -> lj' (gsa/calibrators.py:79) as (phi, pre, alpha index) per (l, J):
+    Lambda^2 = ell_l^2 with J = 0 only when F is diagonal (:105), ell_l ell_J otherwise (:107); phi = 1/(Lambda^2 + 1) (:92);
+    pre = F sqrt(prod Lambda^2 phi) (:86). Returns phi (L, Lb, M), pre (L, Lb) and, for every (l, J), which alpha it multiplies."""
+    L = K_inv_Y.shape[0]
+    ell = np.asarray(lengthscales, dtype=np.float64)
+    if is_F_diagonal:
+        lam2 = (ell * ell)[:, None, :]
+        Fm = np.asarray(F, dtype=np.float64).reshape(L, 1)
+        which = np.arange(L)[:, None]                      # g0KY[l, 0] = g0[l, 0] * K_inv_Y[l]
+    else:
+        lam2 = ell[:, None, :] * ell[None, :, :]
+        Fm = np.asarray(F, dtype=np.float64).reshape(L, L)
+        which = np.broadcast_to(np.arange(L)[None, :], (L, L))   # K_inv_Y transposed to (1, L, N) (:138): g0KY[l, J] = g0[l, J] * K_inv_Y[J]
+    phi = 1.0 / (lam2 + 1.0)
+    pre = Fm * np.sqrt(np.prod(lam2 * phi, axis=-1))
+    return phi, pre, which
+
+
+def covariant_V(handle: '_lib.RcGP', K_inv_Y: np.ndarray, F: np.ndarray, lengthscales: np.ndarray, slices: Sequence[Sequence[int]],
+                is_F_diagonal: bool = False) -> np.ndarray:
+    """(len(slices), L, L) conditional variances from the generic pair entry of the library (``rcgp_sobol_pair``): every weight
+    vector is built on the device from (phi, pre, alpha, shift), the shift being the mean over (J, N) for its l (:90). Any handle
+    on the same X serves. V is symmetric in (l, j)."""
+    alpha = np.ascontiguousarray(np.asarray(K_inv_Y, dtype=np.float64).reshape(-1, handle.N))
+    L = alpha.shape[0]
+    phi, pre, which = _virtual_outputs(alpha, F, np.broadcast_to(lengthscales, (L, handle.M)), is_F_diagonal)
+    Lb = phi.shape[1]
+    sums = np.array([[_lib.sobol_weight_sum(handle, phi[l, J], pre[l, J], alpha[which[l, J]]) for J in range(Lb)] for l in range(L)])
+    shift = sums.sum(axis=1) / float(Lb * handle.N)
+    V = np.zeros((len(slices), L, L))
+    for l in range(L):
+        for j in range(l + 1):
+            for a in range(Lb):
+                for b in range(Lb):
+                    V[:, l, j] += _lib.sobol_pair(handle, phi[l, a], pre[l, a], alpha[which[l, a]], shift[l],
+                                                  phi[j, b], pre[j, b], alpha[which[j, b]], shift[j], slices)
+            V[:, j, l] = V[:, l, j]
+    return V
+
+
 class ClosedSobol(Calibrator):
-    """Closed Sobol conditional variances V and indices S = V / V[2] of a fitted independent-output GP."""
+    """Closed Sobol conditional variances V and indices S = V / V[2] of a fitted GP: independent outputs (one handle call per
+    output pair), or a covariant GP -- with F reduced to its diagonal unless the kernel covariance was trained, as the reference
+    decides from meta.json (gsa/calibrators.py:129-138)."""
 
     @classmethod
     @property
@@ -31,10 +75,14 @@ class ClosedSobol(Calibrator):
         if self.is_F_diagonal is None:
             gp_options = gp.read_meta() if gp._meta_json.exists() else gp.META
             self.is_F_diagonal = not gp_options.get('kernel', {}).get('covariance', False)      # gsa/calibrators.py:129-132
-        if not self.is_F_diagonal:
-            raise NotImplementedError('non-diagonal kernel variance F (covariant GP) is outside this backend')
+        self.is_gp_covariant = bool(getattr(gp, '_is_covariant', False))
+        if not self.is_F_diagonal and not self.is_gp_covariant:
+            raise NotImplementedError('a non-diagonal F needs the (L,L) kernel variance of a covariant GP')
         F = np.asarray(gp.kernel.data.frames.variance.np, dtype=np.float64)
-        self.F = (F if F.shape[0] == 1 else np.diag(F)).reshape(self.L)                          # :134-136
+        if self.is_F_diagonal:
+            self.F = (F if F.shape[0] == 1 else np.diag(F)).reshape(self.L)                      # :134-136
+        else:
+            self.F = F.reshape(self.L, self.L)
         self.Lambda = np.broadcast_to(np.asarray(gp.kernel.data.frames.lengthscales.np, dtype=np.float64), (self.L, self.M)).copy()
         self.K_inv_Y = np.asarray(gp.K_inv_Y, dtype=np.float64).reshape(self.L, self.N)          # also leaves each alpha cached on host
         self._cache: Dict[Tuple[int, int], np.ndarray] = {}
@@ -45,7 +93,12 @@ class ClosedSobol(Calibrator):
         """(L, L, len(slices)) conditional variances; results are memoised per slice."""
         slices = [(int(s[0]), int(s[1])) for s in slices]
         missing = [s for s in dict.fromkeys(slices) if s not in self._cache]
-        if missing:
+        if missing and self.is_gp_covariant:
+            # one (LN) system behind K_inv_Y: every V_lj is a sum of generic pair forms (covariant_V)
+            block = covariant_V(self.gp._select_mo(), self.K_inv_Y, self.F, self.Lambda, missing, self.is_F_diagonal)
+            for i, s in enumerate(missing):
+                self._cache[s] = block[i]
+        elif missing:
             block = np.empty((self.L, self.L, len(missing)))
             for l in range(self.L):
                 handle = self.gp._select(l)
@@ -134,7 +187,9 @@ class ClosedSobolWithError(ClosedSobol):
     def _calibrate(self):
         super()._calibrate()
         if not self.is_F_diagonal:
-            raise NotImplementedError('If the MOGP kernel covariance is not diagonal, the Sobol error calculation is unstable.')
+            raise NotImplementedError('If the MOGP kernel covariance is not diagonal, the Sobol error calculation is unstable.')   # :380-381
+        if self.is_gp_covariant:
+            raise NotImplementedError('Sobol errors of a covariant GP (psi_factor on the (LN) Cholesky factor) are not built on this backend')
         M = self.M
         self._W_diag: Dict[Tuple[int, int], np.ndarray] = {}
         self._W_mixed: Dict[Tuple[int, int], np.ndarray] = {}

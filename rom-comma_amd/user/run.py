@@ -33,8 +33,9 @@ def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | 
         is_calibrated: bool = True, is_tested: bool = True, **kwargs: Any) -> List[str]:
     """GPR on a Fold, or across the Folds of a Repository (sharded over ranks when distributed).
 
-    ``is_read`` None = warm start from the nearest calibrated ancestor ('.i' before '.a'); ``is_isotropic`` None = run
-    isotropic then anisotropic; ``is_covariant`` must be False or None-resolved-to-False on this backend. Returns the model names.
+    ``is_read`` None = warm start from the nearest calibrated ancestor (the independent '.v' model of the same isotropy before
+    the '.i' model, user/run.py:75-84); ``is_isotropic`` None = run isotropic then anisotropic; ``is_covariant`` None = run the
+    independent GPs, then the covariant GP warm-started from them (user/run.py:69-73). Returns the model names.
     """
     if not isinstance(repo, Fold):
         names: List[str] = []
@@ -54,7 +55,10 @@ def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | 
         results.Collect({'variance': {}, 'lengthscales': {}}, {f'{n}/kernel': {} for n in names}, ignore_exceptions).from_folds(repo, True)
         return names
     if is_covariant is None:
-        is_covariant = False            # the reference would run independent then dependent (user/run.py:69-73); dependent GPs are out of scope
+        names = gpr(name, repo, is_read, False, is_isotropic, ignore_exceptions, kernel_parameters, likelihood_variance, is_calibrated, is_tested,
+                    **kwargs)
+        return names + gpr(name, repo, None, True, False if is_isotropic is None else is_isotropic, ignore_exceptions, kernel_parameters,
+                           likelihood_variance, is_calibrated, is_tested, **kwargs)
     full_name = name + ('.c' if is_covariant else '.v')
     if is_isotropic is None:
         names = gpr(name, repo, is_read, is_covariant, True, ignore_exceptions, kernel_parameters, likelihood_variance, is_calibrated, is_tested, **kwargs)
@@ -63,7 +67,9 @@ def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | 
     full_name = full_name + ('.i' if is_isotropic else '.a')
     if is_read is None:
         if not (repo.folder / full_name).exists():
-            nearest_name = full_name[:-2] + '.i'
+            nearest_name = name + '.v' + full_name[-2:]
+            if not (is_covariant and (repo.folder / nearest_name).exists()):
+                nearest_name = full_name[:-2] + '.i'
             if not (repo.folder / nearest_name).exists():
                 return gpr(name, repo, False, is_covariant, is_isotropic, ignore_exceptions, kernel_parameters, likelihood_variance,
                            is_calibrated, is_tested, **kwargs)
@@ -106,6 +112,8 @@ def Y_splits_sharded(repo: Repository) -> List[Repository]:
 
 
 def _names(name: str, is_covariant: Optional[bool], is_isotropic: Optional[bool]) -> List[str]:
+    if is_covariant is None:
+        return _names(name, False, is_isotropic) + _names(name, True, False if is_isotropic is None else is_isotropic)
     base = name + ('.c' if is_covariant else '.v')
     return [base + '.i', base + '.a'] if is_isotropic is None else [base + ('.i' if is_isotropic else '.a')]
 
@@ -131,8 +139,10 @@ def gsa(name: str, repo: Repository, is_covariant: Optional[bool], is_isotropic:
         for n in names:
             shutil.copyfile(repo.fold_folder(repo.folds.start) / n / 'meta.json', repo.folder / n / 'meta.json')
         return names
-    if is_covariant is None:
-        is_covariant = False
+    if is_covariant is None:                                 # independent then covariant (user/run.py:137-140)
+        names = gsa(name, repo, False, is_isotropic, kinds, m, ignore_exceptions, is_error_calculated, **kwargs)
+        return names + gsa(name, repo, True, False if is_isotropic is None else is_isotropic, kinds, m, ignore_exceptions,
+                           is_error_calculated, **kwargs)
     full_name = name + ('.c' if is_covariant else '.v')
     if is_isotropic is None:
         names = gsa(name, repo, is_covariant, True, kinds, m, ignore_exceptions, is_error_calculated, **kwargs)

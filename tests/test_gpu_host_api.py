@@ -138,3 +138,69 @@ def test_predict_gradient(gpu, tmp_path):
         fd = (gp.predict(xp, False)[0] - gp.predict(xm, False)[0]) / (2 * h)
         np.testing.assert_allclose(mean[:, :, m], fd, rtol=1e-5, atol=1e-7)
     gp.close()
+
+
+def test_covariant_gp_end_to_end(gpu, tmp_path):
+    """run.gpr with is_covariant=None: the independent GPs, then the covariant GP warm-started from them (user/run.py:69-84) with
+    the reference's default trainables (kernel Cholesky diagonal + likelihood Cholesky factor); stored parameters, LML, predict
+    and the Sobol indices (diagonal F, then the full F) against oracle/mogp_oracle.py at the fitted hyper-parameters."""
+    from oracle import mogp_oracle as mo
+    from romcomma_amd.data.storage import Fold
+    from romcomma_amd.gpr.models import MOGP
+    from romcomma_amd.gsa.models import GSA, Sobol
+    from romcomma_amd.user import run
+    repo = make_repo(tmp_path / 'repo', N=200, M=3, L=2, seed=4).into_K_folds(-2, seed=5)
+    names = run.gpr('gpr', repo, is_read=False, is_covariant=None, is_isotropic=False)
+    assert names == ['gpr.v.a', 'gpr.c.a']
+    fold = Fold(repo, 0)
+    v = MOGP('gpr.v.a', fold, True, False, False)
+    lml_independent = float(np.sum(v.likelihood.data.frames.log_marginal.np))
+    ell_v = v.kernel.data.frames.lengthscales.np.copy()
+    v.close()
+    # as written by calibrate; constructing the model below re-broadcasts the likelihood variance, which keeps only its diagonal
+    # and rewrites the file (base/classes.py:72-89 through gpr/models.py:284)
+    Sigma_fitted = pd.read_csv(fold.folder / 'gpr.c.a' / 'likelihood' / 'variance.csv', index_col=0).values
+    gp = MOGP('gpr.c.a', fold, True, True, False)
+    ell = gp.kernel.data.frames.lengthscales.np
+    F = gp.kernel.data.frames.variance.np
+    Sigma_stored = gp.likelihood.data.frames.variance.np
+    assert ell.shape == (2, 3) and F.shape == (2, 2) and Sigma_stored.shape == (2, 2)
+    np.testing.assert_array_equal(ell, ell_v)                                  # lengthscales are not trained by default
+    assert F[0, 1] == 0.0 and F[1, 0] == 0.0                                   # nor is the kernel covariance
+    meta = json.loads((fold.folder / 'gpr.c.a' / 'meta.json').read_text())
+    assert meta['kernel']['covariance'] is False and meta['likelihood']['covariance'] is True
+    stored_lml = float(gp.likelihood.data.frames.log_marginal.np[0, 0])
+    assert Sigma_fitted[0, 1] != 0.0 and Sigma_stored[0, 1] == 0.0
+    np.testing.assert_allclose(np.diag(Sigma_stored), np.diag(Sigma_fitted), rtol=1e-12)
+    # the stored LML is the value at the full fitted Sigma
+    assert stored_lml == pytest.approx(mo.lml(gp.X, gp.Y, ell, F, (Sigma_fitted + Sigma_fitted.T) / 2), rel=1e-8)
+    assert stored_lml >= lml_independent - 1e-6 * abs(lml_independent)
+    Sigma = np.diag(np.diag(Sigma_stored))
+    assert gp.log_marginal_likelihood()[0] == pytest.approx(mo.lml(gp.X, gp.Y, ell, F, Sigma), rel=1e-9)
+    x = fold.test_x.values
+    mean, sd = gp.predict(x)
+    mr, sr = mo.predict(gp.X, gp.Y, ell, F, Sigma, x)
+    np.testing.assert_allclose(mean, mr, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(sd, sr, rtol=1e-7)
+    assert np.max(gp.check_K_inv_Y(x[:10])) < 1e-8
+    assert gp.K_inv_Y.shape == (2, 1, gp.N)
+    np.testing.assert_allclose(gp.K_inv_Y, mo.k_inv_y(gp.X, gp.Y, ell, F, Sigma), rtol=1e-6, atol=1e-8)
+    assert (fold.folder / 'gpr.c.a' / 'test_summary.csv').exists()
+    # Sobol on the covariant GP: F diagonal by default (kernel covariance untrained), the full F on request
+    KiY = mo.k_inv_y(gp.X, gp.Y, ell, F, Sigma)
+    sobol = Sobol(gp, GSA.Kind.CLOSED)
+    sobol.calibrate()
+    alpha = KiY.reshape(2, -1)
+    ref = o.ClosedSobolOracle(gp.X, alpha[:, None, :], np.diag(F)[None, :], ell)
+    expect = o.gsa_calibrate(ref, o.CLOSED, 3)
+    np.testing.assert_allclose(sobol.results['S'], expect['S'], rtol=1e-6, atol=1e-9)
+    from romcomma_amd.gsa.calibrators import ClosedSobol
+    full = ClosedSobol(gp, is_F_diagonal=False)
+    slices = [(0, 3), (0, 1), (1, 2), (2, 3), (1, 3), (0, 2)]
+    lit = mo.sobol_V_covariant(gp.X, KiY, F, ell, slices)
+    got = full.marginalize_all(slices)['V']
+    np.testing.assert_allclose(np.moveaxis(got, -1, 0), lit, rtol=1e-7, atol=1e-10 * np.max(np.abs(lit)))
+    gp.close()
+    gsa_names = run.gsa('gpr', repo, is_covariant=True, is_isotropic=False, kinds=GSA.Kind.FIRST_ORDER)
+    assert [str(n) for n in gsa_names] == ['gpr.c.a/gsa/first_order']
+    assert (repo.folder / 'gpr.c.a' / 'gsa' / 'first_order' / 'S.csv').exists()

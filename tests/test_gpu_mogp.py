@@ -1,0 +1,147 @@
+"""GPU parity of the covariant (dependent multi-output) GP path against oracle/mogp_oracle.py, through the C ABI
+(rcgp_create_mo, rcgp_set_hyper_mo, rcgp_lml_grad_mo, rcgp_predict_mo, rcgp_sobol_pair). Parity unpinned (see the oracle)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(N, M, L, seed=0):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, M))
+    W = rng.standard_normal((M, L))
+    Y = np.sin(X @ W) + 0.1 * rng.standard_normal((N, L))
+    if N > 1:
+        Y = (Y - Y.mean(0)) / Y.std(0)
+    ell = 0.7 + 1.5 * rng.random((L, M))
+    C = np.tril(0.4 * rng.standard_normal((L, L)), -1) + np.diag(0.8 + rng.random(L))
+    Cn = np.tril(0.03 * rng.standard_normal((L, L)), -1) + np.diag(0.1 + 0.1 * rng.random(L))
+    F, S = C @ C.T, Cn @ Cn.T
+    return X, Y, ell, (F + F.T) / 2, (S + S.T) / 2
+
+
+@pytest.mark.parametrize('N,M,L', [(200, 3, 2), (130, 4, 3), (128, 2, 2), (1, 2, 2)])
+def test_gram_factor_and_alpha(N, M, L):
+    from oracle import mogp_oracle as mo
+    from romcomma_amd import _lib
+    X, Y, ell, F, S = _case(N, M, L)
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, S)
+        K = gp.gram()
+        Kref = mo.noisy_gram(X, ell, F, S)
+        assert np.abs(K - Kref).max() <= 1e-13 * np.abs(Kref).max()
+        Lc = gp.k_cho()
+        assert np.abs(Lc - mo.k_cho(X, ell, F, S)).max() <= 1e-10
+        assert np.allclose(gp.k_inv_y(), mo.k_inv_y(X, Y, ell, F, S), rtol=1e-8, atol=1e-10)
+        assert gp.lml() == pytest.approx(mo.lml(X, Y, ell, F, S), rel=1e-11)
+
+
+@pytest.mark.parametrize('N,M,L', [(200, 3, 2), (130, 4, 3), (700, 5, 2)])
+def test_lml_gradient(N, M, L):
+    from oracle import mogp_oracle as mo
+    from romcomma_amd import _lib
+    X, Y, ell, F, S = _case(N, M, L, seed=3)
+    v, dF, dell, dS = mo.lml_and_grad(X, Y, ell, F, S)
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, S)
+        lml, gF, gell, gS = gp.lml_grad()
+    assert lml == pytest.approx(v, rel=1e-11)
+    for got, ref in ((gF, dF), (gell, dell), (gS, dS)):
+        assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
+
+
+def test_one_output_limit_is_the_independent_gp():
+    from romcomma_amd import _lib
+    X, Y, ell, F, S = _case(300, 4, 1, seed=5)
+    Xs = np.random.default_rng(9).standard_normal((40, 4))
+    with _lib.RcGP(X, Y[:, 0]) as a, _lib.RcMOGP(X, Y) as b:
+        a.set_hyper(ell[0], F[0, 0], S[0, 0])
+        b.set_hyper(ell, F, S)
+        la, ga = a.lml_grad()
+        lb, gF, gell, gS = b.lml_grad()
+        assert la == lb                                                  # same kernels, same order
+        assert np.allclose(ga, np.r_[gell[0], gF[0, 0], gS[0, 0]], rtol=1e-11, atol=1e-12)
+        ma, sa = a.predict(Xs)
+        mb, sb = b.predict(Xs)
+        assert np.array_equal(ma, mb[:, 0]) and np.array_equal(sa, sb[:, 0])
+
+
+@pytest.mark.parametrize('y_instead_of_f', [True, False])
+def test_predict(y_instead_of_f):
+    from oracle import mogp_oracle as mo
+    from romcomma_amd import _lib
+    X, Y, ell, F, S = _case(260, 3, 3, seed=7)
+    Xs = np.random.default_rng(11).standard_normal((150, 3))
+    mean, sd = mo.predict(X, Y, ell, F, S, Xs, y_instead_of_f)
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, S)
+        m, s = gp.predict(Xs, y_instead_of_f)
+    assert np.allclose(m, mean, rtol=1e-9, atol=1e-10)
+    assert np.allclose(s, sd, rtol=1e-8, atol=1e-10)
+
+
+def test_many_panels_use_the_look_ahead_cholesky():
+    """L N large enough for the fine-grained multi-stream factorisation (Np >= 512) with ragged output blocks."""
+    from oracle import mogp_oracle as mo
+    from romcomma_amd import _lib
+    X, Y, ell, F, S = _case(1100, 6, 3, seed=13)
+    v, dF, dell, dS = mo.lml_and_grad(X, Y, ell, F, S)
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, S)
+        lml, gF, gell, gS = gp.lml_grad()
+        alpha = gp.k_inv_y()
+    assert lml == pytest.approx(v, rel=1e-10)
+    assert np.abs(gell - dell).max() <= 1e-7 * max(1.0, np.abs(dell).max())
+    assert np.abs(gF - dF).max() <= 1e-7 * max(1.0, np.abs(dF).max())
+    assert np.abs(gS - dS).max() <= 1e-7 * max(1.0, np.abs(dS).max())
+    assert np.allclose(alpha, mo.k_inv_y(X, Y, ell, F, S), rtol=1e-6, atol=1e-8)
+
+
+def test_single_output_entries_refuse_a_covariant_handle():
+    from romcomma_amd import _lib
+    X, Y, ell, F, S = _case(64, 2, 2)
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, S)
+        with pytest.raises(_lib.RcgpError):
+            _lib.RcGP.lml_grad(gp)
+        with pytest.raises(_lib.RcgpError):
+            _lib.RcGP.set_hyper(gp, ell[0], 1.0, 0.1)
+        with pytest.raises(_lib.RcgpError):
+            gp.set_hyper(ell, np.array([[1.0, 0.2], [0.3, 1.0]]), S)     # not symmetric
+
+
+def test_not_positive_definite_is_reported():
+    from romcomma_amd import _lib
+    X, Y, ell, F, S = _case(100, 2, 2)
+    F = np.array([[1.0, 3.0], [3.0, 1.0]])                                 # indefinite output covariance
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, 1e-6 * np.eye(2))
+        with pytest.raises(_lib.NotPositiveDefiniteError):
+            gp.lml()
+
+
+def test_sobol_pair_and_covariant_sum():
+    from oracle import gp_oracle as go, mogp_oracle as mo
+    from romcomma_amd import _lib
+    from romcomma_amd.gsa.calibrators import covariant_V
+    X, Y, ell, F, S = _case(300, 4, 2, seed=17)
+    M = 4
+    slices = go.all_slices(M) + [(1, 3), (M, M)]
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, S)
+        KiY = gp.k_inv_y()
+        g, phi = mo.sobol_prepare_covariant(X, KiY, F, ell)
+        # one raw pair against the oracle's pair form
+        lam = ell[0] * ell[1]
+        pre = F[0, 1] * np.sqrt(np.prod(lam * phi[0, 1]))
+        total = _lib.sobol_weight_sum(gp, phi[0, 1], pre, KiY[1, 0])
+        g01 = pre * np.exp(-0.5 * (X * X) @ phi[0, 1]) * KiY[1, 0]
+        assert total == pytest.approx(g01.sum(), rel=1e-11, abs=1e-13)
+        shift = 0.123
+        V = _lib.sobol_pair(gp, phi[0, 1], pre, KiY[1, 0], shift, phi[0, 1], pre, KiY[1, 0], shift, slices)
+        ref = go.sobol_V_pair(X, g01 - shift, g01 - shift, phi[0, 1], phi[0, 1], slices)
+        assert np.allclose(V, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+        # the full covariant V against the oracle
+        Vc = covariant_V(gp, KiY, F, ell, slices)
+    ref = mo.sobol_V_covariant(X, KiY, F, ell, slices)
+    assert np.allclose(Vc, ref, rtol=1e-8, atol=1e-11 * np.abs(ref).max())

@@ -169,12 +169,17 @@ def test_synthetic_cv_folds():
         synthetic_cv_fold(700, 3, 8, K=8)
 
 
-def test_hipgp_refuses_covariant_and_missing_gpu(tmp_path):
+def test_hipgp_stores_and_missing_gpu(tmp_path):
     from romcomma_amd import _lib
     from romcomma_amd.gpr.models import MOGP
     repo = make_repo(tmp_path / 'repo').into_K_folds(-2, seed=0)
+    cov = MOGP('gpr.c.a', Fold(repo, 0), False, True, False)           # covariant: (L,L) variances, diagonal to start with
+    assert cov.kernel.data.frames.variance.np.shape == (2, 2) and cov.likelihood.data.frames.variance.np.shape == (2, 2)
+    assert np.array_equal(cov.kernel.data.frames.variance.np, 2.0 * np.eye(2)) and cov.likelihood.is_covariant and cov.kernel.is_covariant
+    lengthscales, variance, noise = cov._hyper_mo()
+    assert lengthscales.shape == (2, 3) and np.array_equal(noise, 0.02 * np.eye(2)) and len(cov.kernel.implementation) == 1
     with pytest.raises(NotImplementedError):
-        MOGP('gpr.c.a', Fold(repo, 0), False, True, False)
+        cov.predict_gradient(np.zeros((2, 3)))
     gp = MOGP('gpr.v.a', Fold(repo, 0), False, False, False)           # building the stores needs no GPU
     layout = sorted(str(p.relative_to(gp.folder)) for p in gp.folder.rglob('*.csv'))
     assert layout == ['kernel.csv', 'kernel/lengthscales.csv', 'kernel/variance.csv', 'likelihood/log_marginal.csv', 'likelihood/variance.csv']
