@@ -104,6 +104,12 @@ int rcgp_set_hyper_mo(rcgp_handle h, const double* ell, const double* F, const d
 int rcgp_lml_grad_mo(rcgp_handle h, double* lml, double* g_ell, double* g_F, double* g_Sigma);
 /* MOGPR.predict_f / predict_y without full covariances (gpf/models.py:84-113, gpr/models.py:377-384): mean and SD as (n, L). */
 int rcgp_predict_mo(rcgp_handle h, int64_t n, const double* Xnew, int include_noise, double* mean, double* sd);
+/* Gradient GP of a covariant GP (gpr/models.py:386-415, covariant branch). Row r = (l * n + o) * M + m stands for d/dx_om of output l
+ * at point o. mean[r] = sum_{(Lb,N)} dK[(Lb,N)][r] alpha[(Lb,N)]; cov[Lb][r][r'] = sum_N V[(Lb,N)][r] V[(Lb,N)][r'] with
+ * V = L^-1 dK, ONE product per training output block Lb -- the reference's einsum 'LNlOM, LNlom -> OLolMm' (:398) keeps that index.
+ * cov holds L * (L n M)^2 doubles; the caller applies the sign, picks l = l' and adds the diagonal term (:399-400, :406).
+ * L * n * M <= 4096. */
+int rcgp_predict_gradient_mo(rcgp_handle h, int64_t n, const double* Xnew, double* mean, double* cov);
 /* Closed-form Sobol with a non-diagonal F (gsa/calibrators.py:60-97 with is_F_diagonal false) works on "virtual outputs"
  * p = (l, J): phi_p = 1/(ell_l ell_J + 1), pre_p = F[l][J] sqrt(prod_m ell_lm ell_Jm phi_pm), alpha_p = K_inv_Y[J]. Weight vector
  * g_p[n] = pre_p exp(-1/2 sum_m phi_pm x_nm^2) alpha_p[n] - shift_p, the shift being the mean over (J, n) for that l (:90).

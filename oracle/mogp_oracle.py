@@ -166,6 +166,34 @@ def check_k_inv_y(X, Y, ell, F, Sigma, Xs) -> np.ndarray:
     return np.sqrt(np.sum(r * r, axis=0) / o)
 
 
+def predict_gradient(X, Y, ell, F, Sigma, xs) -> Tuple[np.ndarray, np.ndarray]:
+    """MOGP.predict_gradient, covariant branch (gpr/models.py:386-415), with the analytic Jacobian of K(X, x) in place of
+    tape.jacobian: mean (o, L, M) and var (o, L, o, L, M, M). As written in the reference, 'LNlOM, LNlom -> OLolMm' (:398) sums the
+    Cholesky-solved rows over N only, so the first L of var is the TRAINING output block; that is restated, not corrected."""
+    X = np.asarray(X, dtype=np.float64)
+    xs = np.asarray(xs, dtype=np.float64)
+    ell = np.asarray(ell, dtype=np.float64)
+    F = np.asarray(F, dtype=np.float64)
+    L, (N, M), o = F.shape[0], X.shape, xs.shape[0]
+    Lc = k_cho(X, ell, F, Sigma)
+    KiY = k_inv_y(X, Y, ell, F, Sigma)
+    U = X[None, :, :] / ell[:, None, :]
+    u = xs[None, :, :] / ell[:, None, :]
+    d = U[:, :, None, None, :] - u[None, None, :, :, :]                           # (L, N, l, o, M)
+    K = F[:, None, :, None] * np.exp(-0.5 * np.einsum('...M,...M->...', d, d))
+    dK = K[..., None] * d / ell[None, None, :, None, :]                           # d K[(L,N),(l,o)] / d x_oM   (:393-395)
+    mean = np.einsum('LNloM,LiN->olM', dK, KiY)                                   # :396
+    V = scipy.linalg.solve_triangular(Lc, dK.reshape(L * N, L * o * M), lower=True, check_finite=False).reshape(L, N, L, o, M)   # :397
+    var = -np.einsum('LNlOM,LNlom->OLolMm', V, V)                                 # :398
+    Lambda = np.broadcast_to(1.0 / ell, (o, L, M))                                # :388
+    dd = u[:, :, None, None, :] - u[None, None, :, :, :]
+    kxx = F[:, None, :, None] * np.exp(-0.5 * np.einsum('...M,...M->...', dd, dd))    # kernel(x) as (L, o, L, o)
+    ddxxkxx = np.einsum('OLM,olM,LOlo->OLolM', Lambda, Lambda, kxx)               # :399-400
+    idx = np.arange(M)
+    var[..., idx, idx] += ddxxkxx                                                 # :406
+    return mean, var
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # Variance parametrisation (gpf/base.py:32-96) and the fit (gpr/models.py:345-373, gpr/kernels.py:59-70, gpr/models.py:71-80)
 # --------------------------------------------------------------------------------------------------------------------

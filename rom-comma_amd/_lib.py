@@ -42,6 +42,7 @@ SIGNATURES = {
     'rcgp_set_hyper_mo': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
     'rcgp_lml_grad_mo': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'rcgp_predict_mo': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    'rcgp_predict_gradient_mo': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p]),
     'rcgp_sobol_weight_sum': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p]),
     'rcgp_sobol_pair': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
                                        _c_double_p, ctypes.c_double, ctypes.c_int, _c_int32_p, _c_double_p]),
@@ -336,8 +337,16 @@ class RcMOGP(RcGP):
         self._check(self._lib.rcgp_predict_mo(self._h, n, _dp(Xnew), int(bool(include_noise)), _dp(mean), _dp(sd)), 'rcgp_predict_mo')
         return mean, sd
 
-    def predict_gradient(self, Xnew):
-        raise NotImplementedError('predict_gradient is not available for a covariant GP on this backend')
+    def predict_gradient(self, Xnew) -> Tuple[np.ndarray, np.ndarray]:
+        """(mean (L, n, M), cov (L_train, L, n, M, L, n, M)): cov[Lb] = V_Lb^T V_Lb over the rows of training output block Lb only."""
+        Xnew = _f64(Xnew)
+        if Xnew.ndim != 2 or Xnew.shape[1] != self.M:
+            raise ValueError('Xnew must be (n, M)')
+        n = Xnew.shape[0]
+        R = self.L * n * self.M
+        mean, cov = np.empty(R), np.empty((self.L, R, R))
+        self._check(self._lib.rcgp_predict_gradient_mo(self._h, n, _dp(Xnew), _dp(mean), _dp(cov)), 'rcgp_predict_gradient_mo')
+        return mean.reshape(self.L, n, self.M), cov.reshape(self.L, self.L, n, self.M, self.L, n, self.M)
 
     def sobol_closed(self, slices):
         raise NotImplementedError('use sobol_covariant on a covariant GP')

@@ -531,6 +531,7 @@ RC_API int rcgp_predict_gradient(rcgp_handle h, int64_t n, const double* Xnew, d
     RC_HIP(hipMalloc(&h->gV, (size_t)Np * rows_padded * sizeof(double)));
     RC_HIP(hipMalloc(&h->gC, (size_t)rows_padded * rows_padded * sizeof(double)));
     h->g_rows = rows_padded;
+    h->g_blocks = 1;
   }
   const int64_t np = ((n + 127) / 128) * 128;
   if ((rc = upload_padded(h, h->Xs, Xnew, n, np, M))) return rc;
@@ -547,6 +548,66 @@ RC_API int rcgp_predict_gradient(rcgp_handle h, int64_t n, const double* Xnew, d
   RC_HIP(hipMemcpyAsync(mean, h->pmean, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   RC_HIP(hipMemcpy2DAsync(cov, (size_t)rows * sizeof(double), h->gC, (size_t)rows_padded * sizeof(double), (size_t)rows * sizeof(double),
                           (size_t)rows, hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// Covariant GP: row r = (l * n + o) * M + m holds d K[(Lb, N), (l, o)] / d x_om = -(u_m - U_m) / ell_lm * F[Lb][l] exp(-1/2 |U - u|^2) with
+// U = X_N / ell_Lb and u = x_o / ell_l (Zs holds the L * n scaled points output-major); zero on the padding.
+__global__ void k_dkernel_rows_mo(const double* __restrict__ Zs, const double* __restrict__ sqs, const double* __restrict__ Z,
+                                  const double* __restrict__ sq, const double* __restrict__ ell, const double* __restrict__ F, int L,
+                                  int64_t n_pts, int64_t N, int64_t Nb, int64_t Np, int M, double* __restrict__ D) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (a >= Np) return;
+  const int64_t p = r / M;                                 // scaled point (l, o)
+  const int m = (int)(r - p * M);
+  const int64_t l = p / n_pts;
+  const int64_t Lb = a / Nb;
+  double v = 0.0;
+  if (l < L && a - Lb * Nb < N) {
+    double dot = 0.0;
+    for (int mm = 0; mm < M; ++mm) dot = fma(Zs[p * M + mm], Z[a * M + mm], dot);
+    const double k = F[Lb * L + l] * exp(sqs[p] + sq[a] + dot);
+    v = -(Zs[p * M + m] - Z[a * M + m]) / ell[l * M + m] * k;
+  }
+  D[r * Np + a] = v;
+}
+
+RC_API int rcgp_predict_gradient_mo(rcgp_handle h, int64_t n, const double* Xnew, double* mean, double* cov) {
+  RC_CHECK_H(h);
+  const int M = h->M, L = h->L;
+  if (n < 1 || !Xnew || !mean || !cov) { h->err = "rcgp_predict_gradient_mo: bad argument"; return -2; }
+  const int64_t rows = (int64_t)L * n * M, rows_padded = ((rows + 127) / 128) * 128;
+  if (rows_padded > PRED_CAP) { h->err = "rcgp_predict_gradient_mo: L * n * M exceeds 4096"; return -6; }
+  int rc;
+  if ((rc = rcgp_factor(h))) return rc;
+  if ((rc = rc_ensure_pred(h))) return rc;
+  const int64_t Np = h->Np;
+  if (h->g_rows < rows_padded || h->g_blocks < L) {
+    if (h->gV) { RC_HIP(hipFree(h->gV)); h->gV = nullptr; }
+    if (h->gC) { RC_HIP(hipFree(h->gC)); h->gC = nullptr; }
+    RC_HIP(hipMalloc(&h->gV, (size_t)Np * rows_padded * sizeof(double)));
+    RC_HIP(hipMalloc(&h->gC, (size_t)L * rows_padded * rows_padded * sizeof(double)));
+    h->g_rows = rows_padded;
+    h->g_blocks = L;
+  }
+  if ((rc = upload_padded(h, h->Xs, Xnew, n, n, M))) return rc;
+  for (int l = 0; l < L; ++l)
+    if ((rc = rc_launch_scale_rows(h, h->Xs, h->Zs + (size_t)l * n * M, h->sqs + (size_t)l * n, n, l))) return rc;
+  {
+    RcProfScope ps(h, RC_K_MISC, 0.0);
+    hipLaunchKernelGGL(k_dkernel_rows_mo, dim3((unsigned)((Np + 255) / 256), (unsigned)rows_padded), dim3(256), 0, h->stream, h->Zs, h->sqs, h->Z,
+                       h->sq, h->ell_d, h->FS_d, L, n, h->N, h->Nb, Np, M, h->KsT);
+    RC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_rowdot, dim3((unsigned)rows), dim3(256), 0, h->stream, h->KsT, Np, h->alpha, Np, h->pmean);
+    RC_HIP(hipGetLastError());
+  }
+  if ((rc = rc_launch_gradient_cov(h, rows_padded, h->gV, h->gC, true))) return rc;
+  RC_HIP(hipMemcpyAsync(mean, h->pmean, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  for (int b = 0; b < L; ++b)
+    RC_HIP(hipMemcpy2DAsync(cov + (size_t)b * rows * rows, (size_t)rows * sizeof(double), h->gC + (size_t)b * rows_padded * rows_padded,
+                            (size_t)rows_padded * sizeof(double), (size_t)rows * sizeof(double), (size_t)rows, hipMemcpyDeviceToHost, h->stream));
   RC_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }

@@ -96,6 +96,7 @@ struct rcgp_handle_s {
   int64_t pred_cap = 0;
   double *gV = nullptr, *gC = nullptr;   // predict_gradient scratch
   int64_t g_rows = 0;
+  int g_blocks = 0;                       // V^T V products gC has room for
   // sobol scratch
   double *sob = nullptr;       // prep arrays
   size_t sob_elems = 0;
@@ -195,7 +196,7 @@ int rc_launch_grad_mo(rcgp_handle_s* h, int* nrows);     // covariant GP: 2M + 2
 int rc_launch_predict_var(rcgp_handle_s* h, int64_t np);
 
 // predict_gradient: V (Np x rows) = Linv * KsT^T stored, C (rows x rows) = V^T V
-int rc_launch_gradient_cov(rcgp_handle_s* h, int64_t rows_padded, double* V, double* C);
+int rc_launch_gradient_cov(rcgp_handle_s* h, int64_t rows_padded, double* V, double* C, bool per_block = false);
 
 // ---- potrf.hip
 int rc_potrf(rcgp_handle_s* h);                              // blocked Cholesky of A in place, w = L^-1 y, logdiag

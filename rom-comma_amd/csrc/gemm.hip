@@ -868,16 +868,18 @@ __global__ void RC_BOUNDS(WN) k_linv_times_rows(const double* __restrict__ Linv,
 }
 
 template <int WN>
-__global__ void RC_BOUNDS(WN) k_vtv(const double* __restrict__ V, int64_t ldv, int64_t Np, double* __restrict__ C, int64_t ldc) {
+__global__ void RC_BOUNDS(WN) k_vtv(const double* __restrict__ V, int64_t ldv, int64_t k0, int64_t k1, double* __restrict__ C, int64_t ldc) {
   __shared__ double lds[GEMM_LDS];
   const int tj = blockIdx.x, ti = blockIdx.y;
   v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
-  gemm_mainloop<false, false, WN>(V, ldv, (int64_t)ti * 128, V, ldv, (int64_t)tj * 128, 0, Np, acc, lds);
+  gemm_mainloop<false, false, WN>(V, ldv, (int64_t)ti * 128, V, ldv, (int64_t)tj * 128, k0, k1, acc, lds);
   acc_store<WN>(acc, C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128, ldc);
 }
 
-int rc_launch_gradient_cov(rcgp_handle_s* h, int64_t rows_padded, double* V, double* C) {
+// C = V^T V over all rows of V; with per_block one product per output block of rows (a covariant GP's predict_gradient keeps
+// the training output index, gpr/models.py:398: 'LNlOM, LNlom -> OLolMm'), stored one after the other in C.
+int rc_launch_gradient_cov(rcgp_handle_s* h, int64_t rows_padded, double* V, double* C, bool per_block) {
   const int64_t T = h->Np / 128, R = rows_padded / 128;
   {
     RcProfScope ps(h, RC_K_GEMM, (double)h->Np * (double)h->Np * (double)rows_padded);
@@ -885,9 +887,12 @@ int rc_launch_gradient_cov(rcgp_handle_s* h, int64_t rows_padded, double* V, dou
                        rows_padded);
     RC_HIP(hipGetLastError());
   }
-  {
-    RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)h->Np * (double)rows_padded * (double)rows_padded);
-    hipLaunchKernelGGL(k_vtv<RC_WN>, dim3((unsigned)R, (unsigned)R), dim3(128 * RC_WN), 0, h->launch, V, rows_padded, h->Np, C, rows_padded);
+  const int nprod = per_block ? h->L : 1;
+  const int64_t span = per_block ? h->Nb : h->Np;
+  for (int b = 0; b < nprod; ++b) {
+    RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)span * (double)rows_padded * (double)rows_padded);
+    hipLaunchKernelGGL(k_vtv<RC_WN>, dim3((unsigned)R, (unsigned)R), dim3(128 * RC_WN), 0, h->launch, V, rows_padded, b * span, (b + 1) * span,
+                       C + (size_t)b * rows_padded * rows_padded, rows_padded);
     RC_HIP(hipGetLastError());
   }
   return 0;

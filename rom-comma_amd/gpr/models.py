@@ -394,9 +394,24 @@ class HipGP(GPR):
         covariance (o, o, L, M, M). As in the reference: mean = dK^T alpha; cov = -(L^-1 dK)^T (L^-1 dK) with
         k(x_O, x_o) / ell_M^2 added where the two gradient components coincide (M == m); ``y_instead_of_f`` is accepted and,
         exactly as in the reference, has no effect. dK = d k(X, x)/dx is analytic here (tape.jacobian in the reference)."""
-        if self._is_covariant:
-            raise NotImplementedError('predict_gradient of a covariant GP (gpr/models.py:392-405) is not built on this backend')
         x = np.ascontiguousarray(x, dtype=np.float64)
+        if self._is_covariant:
+            # covariant branch (gpr/models.py:392-405): mean (o, L, M); var (o, L, o, L, M, M), where the first L is the TRAINING
+            # output block the Cholesky-solved rows belong to -- the reference's einsum 'LNlOM, LNlom -> OLolMm' sums over N only
+            o = x.shape[0]
+            lengthscales, variance, _ = self._hyper_mo()
+            m_lom, cov = self._select_mo().predict_gradient(x)                  # (l, o, M), (Lb, l, O, M, l', o, m)
+            mean = np.transpose(m_lom, (1, 0, 2))
+            same_l = np.einsum('BlOMlom->OBolMm', cov)                          # l' = l
+            var = -same_l
+            u = x[None, :, :] / lengthscales[:, None, :]                        # (L, o, M)
+            d = u[:, :, None, None, :] - u[None, None, :, :, :]
+            kxx = variance[:, None, :, None] * np.exp(-0.5 * np.einsum('...M,...M->...', d, d))      # kernel(x): (L, O, l, o)
+            lam = 1.0 / lengthscales                                            # Lambda (broadcast over the points, :388)
+            ddxxkxx = np.einsum('LM,lM,LOlo->OLolM', lam, lam, kxx)             # :399-400
+            idx = np.arange(self._M)
+            var[..., idx, idx] += ddxxkxx                                       # set_diag(var, diag_part(var) + ddxxkxx) (:406)
+            return mean, var
         o = x.shape[0]
         mean = np.empty((o, self._L, self._M))
         var = np.empty((o, o, self._L, self._M, self._M))

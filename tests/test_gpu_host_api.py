@@ -186,6 +186,11 @@ def test_covariant_gp_end_to_end(gpu, tmp_path):
     assert gp.K_inv_Y.shape == (2, 1, gp.N)
     np.testing.assert_allclose(gp.K_inv_Y, mo.k_inv_y(gp.X, gp.Y, ell, F, Sigma), rtol=1e-6, atol=1e-8)
     assert (fold.folder / 'gpr.c.a' / 'test_summary.csv').exists()
+    gmean, gvar = gp.predict_gradient(x[:4])
+    rmean, rvar = mo.predict_gradient(gp.X, gp.Y, ell, F, Sigma, x[:4])
+    assert gmean.shape == (4, 2, 3) and gvar.shape == (4, 2, 4, 2, 3, 3)
+    np.testing.assert_allclose(gmean, rmean, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(gvar, rvar, rtol=1e-6, atol=1e-9 * np.max(np.abs(rvar)))
     # Sobol on the covariant GP: F diagonal by default (kernel covariance untrained), the full F on request
     KiY = mo.k_inv_y(gp.X, gp.Y, ell, F, Sigma)
     sobol = Sobol(gp, GSA.Kind.CLOSED)

@@ -140,3 +140,21 @@ def test_fit_trains_the_reference_default_subset():
     assert value > start and nfev >= 2
     ell2, F2, S2, value2, _, _ = mo.fit(X, Y, ell, F0, S0, trainable={'kernel_covariance': True, 'lengthscales': True})
     assert value2 >= value - 1e-9 and F2[0, 1] != 0.0 and not np.array_equal(ell2, ell)
+
+
+def test_predict_gradient_mean_is_the_gradient_of_the_posterior_mean():
+    X, Y, ell, F, S = _case(N=25, M=3, L=2, seed=8)
+    xs = np.random.default_rng(9).standard_normal((4, 3))
+    mean, var = mo.predict_gradient(X, Y, ell, F, S, xs)
+    assert mean.shape == (4, 2, 3) and var.shape == (4, 2, 4, 2, 3, 3)
+    for m in range(3):
+        xp, xm = xs.copy(), xs.copy()
+        xp[:, m] += 1e-6
+        xm[:, m] -= 1e-6
+        fd = (mo.predict(X, Y, ell, F, S, xp, False)[0] - mo.predict(X, Y, ell, F, S, xm, False)[0]) / 2e-6
+        assert np.abs(mean[:, :, m] - fd).max() < 1e-6 * max(1.0, np.abs(fd).max())
+    # one output: the independent gradient GP (var[O, 0, o, 0] against the 'OoLMm' layout)
+    X, Y, ell, F, S = _case(N=25, M=3, L=1, seed=8)
+    m1, v1 = mo.predict_gradient(X, Y, ell, F, S, xs)
+    m0, v0 = go.predict_gradient(X, Y[:, 0], ell[0], F[0, 0], S[0, 0], xs)
+    assert np.allclose(m1[:, 0, :], m0, rtol=1e-11, atol=1e-13) and np.allclose(v1[:, 0, :, 0], v0, rtol=1e-9, atol=1e-12)
