@@ -75,8 +75,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     RC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // hi is the numerically lowest = highest priority
     RC_HIP(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
     RC_HIP(hipStreamCreateWithPriority(&h->stream5, hipStreamNonBlocking, hi));
-    if (getenv("RCGP_B2_NORMAL")) RC_HIP(hipStreamCreateWithFlags(&h->stream6, hipStreamNonBlocking));
-    else RC_HIP(hipStreamCreateWithPriority(&h->stream6, hipStreamNonBlocking, hi));
+    RC_HIP(hipStreamCreateWithPriority(&h->stream6, hipStreamNonBlocking, hi));
   }
   {
     // The bulk-update stream may use every CU except the first RCGP_RESERVE_CUS, which stay free for the panel chain.
