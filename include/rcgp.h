@@ -117,6 +117,11 @@ int rcgp_predict_gradient_mo(rcgp_handle h, int64_t n, const double* Xnew, doubl
  * sum_{n,n'} g_a[n] g_b[n'] prod_{m in slice} h_m(n,n'); V_lj is its sum over the virtual outputs (l, .) x (j, .) (:79).
  * Both only use the handle's design matrix X (any handle on the same X will do). */
 int rcgp_sobol_weight_sum(rcgp_handle h, const double* phi /* M */, double pre, const double* alpha /* N */, double* sum);
+/* rcgp_sobol_error_terms for the output pair (out_a, out_b) of a covariant handle whose F is taken as diagonal (the only case
+ * the reference computes errors for, gsa/calibrators.py:380-381): output l is (ell[l], F[l][l], its N entries of K_inv_Y), and
+ * psi_factor solves with the Cholesky factor of the whole (L N) system, the vector sitting in block out_b (:304-308). */
+int rcgp_sobol_error_terms_mo(rcgp_handle h, int out_a, int out_b, int n_slices, const int32_t* slices, double* phi_d, double* psi_d,
+                              double* phi_m, double* psi_m);
 int rcgp_sobol_pair(rcgp_handle h, const double* phi_a, double pre_a, const double* alpha_a, double shift_a, const double* phi_b,
                     double pre_b, const double* alpha_b, double shift_b, int n_slices, const int32_t* slices, double* V);
 

@@ -34,7 +34,8 @@ def _set_diag(matrix, diagonal):
 
 
 class LiteralClosedSobolWithError(LiteralClosedSobol):
-    """gsa/calibrators.py:146-402. ``K_cho`` (L,N,N) is needed here (psi_factor), unlike in plain ClosedSobol."""
+    """gsa/calibrators.py:146-402. ``K_cho`` (L,N,N) is needed here (psi_factor), unlike in plain ClosedSobol; a covariant GP
+    passes its (LN,LN) factor (F still diagonal, :380-381) and takes the rank-2 branch of psi_factor."""
 
     RANK_EQUATIONS = RankEquations(DIAGONAL=(RankEquation(l='j', i='k', j='l', k='i'), RankEquation(l='k', i='j', j='i', k='l')),
                                    MIXED=(RankEquation(l='k', i='k', j='j', k='i'),))                       # :169-170
@@ -130,7 +131,19 @@ class LiteralClosedSobolWithError(LiteralClosedSobol):
         gaussian = Gaussian(mean=mean, variance=D, LBunch=2)
         gaussian = gaussian / GGaussian.expand_dims([-1, -2, -3])
         factor = np.einsum('lLN,iIn,lLNiIn->liIn', self.g0KY, self.g0, gaussian.pdf)
-        # rank(K_cho) == 3 for independent GPs: the diag branch (:305-306) is not taken
+        if self.K_cho.ndim == 2 and factor.shape[-2] == 1:                                           # :304-305, covariant GP with diagonal F:
+            lNi = np.einsum('liIN->lNi', factor)                                                     # the vector goes into block i of (L N)
+            diag = np.zeros(lNi.shape + (lNi.shape[-1],))
+            idx = np.arange(lNi.shape[-1])
+            diag[..., idx, idx] = lNi                                                                # tf.linalg.diag
+            factor = np.einsum('lNiI->liIN', diag)
+            factor = np.reshape(factor, list(factor.shape[:-2]) + [-1, 1])                           # (l, i, L N, 1)
+            out = np.empty(factor.shape[:-1])
+            for l in range(factor.shape[0]):
+                for i in range(factor.shape[1]):
+                    out[l, i] = scipy.linalg.solve_triangular(self.K_cho, factor[l, i, :, 0], lower=True, check_finite=False)
+            return out
+        # rank(K_cho) == 3 for independent GPs: the diag branch is not taken
         factor = np.reshape(factor, list(factor.shape[:-2]) + [-1, 1])                               # (l, i, N, 1)
         out = np.empty(factor.shape[:-1])
         for l in range(factor.shape[0]):

@@ -43,6 +43,8 @@ SIGNATURES = {
     'rcgp_lml_grad_mo': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'rcgp_predict_mo': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]),
     'rcgp_predict_gradient_mo': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p]),
+    'rcgp_sobol_error_terms_mo': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_int32_p, _c_double_p, _c_double_p,
+                                                 _c_double_p, _c_double_p]),
     'rcgp_sobol_weight_sum': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p]),
     'rcgp_sobol_pair': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
                                        _c_double_p, ctypes.c_double, ctypes.c_int, _c_int32_p, _c_double_p]),
@@ -349,9 +351,18 @@ class RcMOGP(RcGP):
         return mean.reshape(self.L, n, self.M), cov.reshape(self.L, self.L, n, self.M, self.L, n, self.M)
 
     def sobol_closed(self, slices):
-        raise NotImplementedError('use sobol_covariant on a covariant GP')
+        raise NotImplementedError('use romcomma_amd.gsa.calibrators.covariant_V on a covariant GP')
 
-    sobol_cross = sobol_error_terms = sobol_closed
+    sobol_cross = sobol_closed
+
+    def sobol_error_terms(self, slices, out_a: int, out_b: int):
+        """(phi_d, psi_d, phi_m, psi_m), each (n_slices,), for the output pair (out_a, out_b) with F taken as diagonal."""
+        s = self._slices(slices)
+        n = s.shape[0]
+        out = [np.empty(n) for _ in range(4)]
+        self._check(self._lib.rcgp_sobol_error_terms_mo(self._h, int(out_a), int(out_b), n, s.ctypes.data_as(_c_int32_p),
+                                                        *[_dp(o) for o in out]), 'rcgp_sobol_error_terms_mo')
+        return tuple(out)
 
 
 def sobol_weight_sum(gp: RcGP, phi, pre: float, alpha) -> float:

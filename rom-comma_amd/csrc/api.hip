@@ -649,6 +649,19 @@ RC_API int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var
   return rc_sobol_error_terms(h, ell_a, var_a, alpha_a, n_slices, slices, phi_d, psi_d, phi_m, psi_m);
 }
 
+RC_API int rcgp_sobol_error_terms_mo(rcgp_handle h, int out_a, int out_b, int n_slices, const int32_t* slices, double* phi_d, double* psi_d,
+                                     double* phi_m, double* psi_m) {
+  RC_CHECK_H(h);
+  if (out_a < 0 || out_a >= h->L || out_b < 0 || out_b >= h->L || n_slices < 0 ||
+      (n_slices > 0 && (!slices || !phi_d || !psi_d || !phi_m || !psi_m))) {
+    h->err = "rcgp_sobol_error_terms_mo: bad argument";
+    return -2;
+  }
+  int rc;
+  if ((rc = rcgp_factor(h))) return rc;
+  return rc_sobol_error_terms(h, nullptr, 0.0, nullptr, n_slices, slices, phi_d, psi_d, phi_m, psi_m, out_a, out_b);
+}
+
 static int check_phi(rcgp_handle_s* h, const double* phi, const char* who) {
   for (int m = 0; m < h->M; ++m)
     if (!(phi[m] > 0.0) || !(phi[m] < 1.0)) { h->err = std::string(who) + ": phi must lie in (0, 1)"; return -2; }

@@ -219,7 +219,7 @@ int rc_sobol(rcgp_handle_s* h, const double* ell_j, double var_j, const double* 
              double* V_host);
 
 int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, const double* alpha_a_host, int n_slices,
-                         const int32_t* slices, double* phi_d, double* psi_d, double* phi_m, double* psi_m);
+                         const int32_t* slices, double* phi_d, double* psi_d, double* phi_m, double* psi_m, int out_a = -1, int out_b = -1);
 
 // ---- util
 int rc_ensure_pred(rcgp_handle_s* h);                        // predict / psi scratch (KsT, pvar, ...)

@@ -230,8 +230,8 @@ static int sobol_make_g(rcgp_handle_s* h, const double* ell, double var, const d
   RC_HIP(hipMemcpyAsync(phi_d, phi_host.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, h->stream));
   RC_HIP(hipStreamSynchronize(h->stream));               // phi_host may be reused by the caller
   RcProfScope ps(h, RC_K_MISC, 0.0);
-  const unsigned nb = (unsigned)((h->Np + 255) / 256);
-  hipLaunchKernelGGL(k_sobol_g0, dim3(nb), dim3(256), 0, h->stream, h->X, alpha_d, phi_d, pre, h->N, h->Np, M, g_d, g0_d);
+  const unsigned nb = (unsigned)((h->Nb + 255) / 256);
+  hipLaunchKernelGGL(k_sobol_g0, dim3(nb), dim3(256), 0, h->stream, h->X, alpha_d, phi_d, pre, h->N, h->Nb, M, g_d, g0_d);
   hipLaunchKernelGGL(k_sum1, dim3(1), dim3(1024), 0, h->stream, g_d, h->N, sum_d);
   hipLaunchKernelGGL(k_sobol_center, dim3(nb), dim3(256), 0, h->stream, g_d, h->N, sum_d);
   hipLaunchKernelGGL(k_sum1, dim3(1), dim3(1024), 0, h->stream, g_d, h->N, sum_d + 1);
@@ -587,8 +587,10 @@ __global__ void k_sobol_gtilde(const double* __restrict__ X, const double* __res
 
 // F rows for the psi terms (row-major [rows][Np] into KsT): r < 3M: g0 * u_r ; 3M <= r < 6M: g0 * (u_{r-3M} + u_full) ;
 // r == 6M: g0 * u_full_bb (the (b,b) full-model vector when a != b, else a copy of row `full`) ; zero beyond.
+// F has leading dimension ldf and the row lands at column offset off: a covariant GP embeds the vector in its output block of the
+// (L N) system, zeros elsewhere (the set_diag / reshape of gsa/calibrators.py:304-306 for a rank-2 K_cho).
 __global__ void k_sobol_psi_rows(const double* __restrict__ U, const double* __restrict__ Ufull, const double* __restrict__ g0,
-                                 int M, int64_t Np, int64_t rows_padded, double* __restrict__ F) {
+                                 int M, int64_t Np, int64_t rows_padded, double* __restrict__ F, int64_t ldf, int64_t off) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
   if (n >= Np) return;
@@ -596,14 +598,26 @@ __global__ void k_sobol_psi_rows(const double* __restrict__ U, const double* __r
   if (r < 3 * M) v = g0[n] * U[(int64_t)r * Np + n];
   else if (r < 6 * M) v = g0[n] * (U[(int64_t)(r - 3 * M) * Np + n] + Ufull[n]);
   else if (r == 6 * M) v = g0[n] * Ufull[n];
-  F[(int64_t)r * Np + n] = v;
+  F[(int64_t)r * ldf + off + n] = v;
 }
 
+// out_b < 0: the handle's single output is b, and a is b itself (ell_a == nullptr) or described by (ell_a, var_a, alpha_a_host).
+// out_b >= 0 (covariant handle, diagonal F): a = output block out_a, b = output block out_b of the handle, each with its own
+// lengthscale row, F[l][l] and its N entries of the joint K_inv_Y; the psi vectors are embedded in block b of the (L N) system.
 int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, const double* alpha_a_host, int n_slices,
-                         const int32_t* slices, double* phi_d_out, double* psi_d_out, double* phi_m_out, double* psi_m_out) {
+                         const int32_t* slices, double* phi_d_out, double* psi_d_out, double* phi_m_out, double* psi_m_out, int out_a,
+                         int out_b) {
   const int M = h->M;
-  const int64_t Np = h->Np, T = Np / 128;
-  const bool self = (ell_a == nullptr);
+  const int64_t Np = h->Nb, T = Np / 128;                        // rows of one output block: the X-side kernels work on those
+  const bool mo = (out_b >= 0);
+  const bool self = mo ? (out_a == out_b) : (ell_a == nullptr);
+  const double* ell_b = h->ell.data() + (mo ? (size_t)out_b * M : 0);
+  const double var_b = mo ? h->Fm[(size_t)out_b * h->L + out_b] : h->var;
+  const double* alpha_b_d = h->alpha + (mo ? (size_t)out_b * h->Nb : 0);
+  if (mo) {
+    ell_a = h->ell.data() + (size_t)out_a * M;
+    var_a = h->Fm[(size_t)out_a * h->L + out_a];
+  }
   if (M > 29) { h->err = "sobol errors: at most 29 input dimensions are supported"; return -6; }
   for (int s = 0; s < n_slices; ++s) {
     const int a = slices[2 * s], b = slices[2 * s + 1];
@@ -633,19 +647,23 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
   double* cu_d = small + 6 * M;
   double* sums_d = small + 7 * M;
   std::vector<double> phi_b, phi_a;
-  if ((rc = sobol_make_g(h, h->ell.data(), h->var, h->alpha, phi_b_d, g_b, sums_d, phi_b, g0_b))) return rc;
+  if ((rc = sobol_make_g(h, ell_b, var_b, alpha_b_d, phi_b_d, g_b, sums_d, phi_b, g0_b))) return rc;
   if (!self) {
-    RC_HIP(hipMemsetAsync(al_a, 0, (size_t)Np * sizeof(double), h->stream));
-    RC_HIP(hipMemcpyAsync(al_a, alpha_a_host, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (mo) {
+      RC_HIP(hipMemcpyAsync(al_a, h->alpha + (size_t)out_a * h->Nb, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+      RC_HIP(hipMemsetAsync(al_a, 0, (size_t)Np * sizeof(double), h->stream));
+      RC_HIP(hipMemcpyAsync(al_a, alpha_a_host, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     if ((rc = sobol_make_g(h, ell_a, var_a, al_a, phi_a_d, g_a, sums_d + 2, phi_a))) return rc;
   } else {
     phi_a = phi_b;
     g_a = g_b;
   }
   std::vector<double> ups_b(M);
-  double pre_b = h->var;
+  double pre_b = var_b;
   for (int m = 0; m < M; ++m) {
-    const double l2 = h->ell[m] * h->ell[m];
+    const double l2 = ell_b[m] * ell_b[m];
     ups_b[m] = 1.0 / (l2 + 2.0);
     pre_b *= sqrt(l2 * ups_b[m]);                                  // gsa/calibrators.py:384
   }
@@ -752,8 +770,9 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
     Ufull_bb = Ubb + (size_t)full * Np;
   }
   const int64_t rows = 6 * M + 1, rows_padded = ((rows + 127) / 128) * 128;
+  if (mo) RC_HIP(hipMemsetAsync(h->KsT, 0, (size_t)rows_padded * h->Np * sizeof(double), h->stream));
   hipLaunchKernelGGL(k_sobol_psi_rows, dim3((unsigned)((Np + 255) / 256), (unsigned)rows_padded), dim3(256), 0, h->stream, U, Ufull_bb, g0_b, M,
-                     Np, rows_padded, h->KsT);
+                     Np, rows_padded, h->KsT, h->Np, mo ? (int64_t)out_b * h->Nb : 0);
   RC_HIP(hipGetLastError());
   if ((rc = rc_launch_predict_var(h, rows_padded))) return rc;
   std::vector<double> pv(rows_padded);

@@ -163,9 +163,11 @@ class ClosedSobolWithError(ClosedSobol):
         D = np.zeros((L, L, len(slices)))
         Mx = np.zeros((L, L, len(slices)))
         for b in range(L):
-            handle = self.gp._select(b)
+            handle = self.gp._select_mo() if self.is_gp_covariant else self.gp._select(b)
             for a in range(L):
-                if a == b:
+                if self.is_gp_covariant:         # both outputs live in the one (LN) system; psi_factor embeds in block b (:304-308)
+                    phi_d, psi_d, phi_m, psi_m = handle.sobol_error_terms(slices, a, b)
+                elif a == b:
                     phi_d, psi_d, phi_m, psi_m = handle.sobol_error_terms(slices)
                 else:
                     phi_d, psi_d, phi_m, psi_m = handle.sobol_error_terms(slices, self.Lambda[a], self.F[a], self.K_inv_Y[a])
@@ -188,8 +190,6 @@ class ClosedSobolWithError(ClosedSobol):
         super()._calibrate()
         if not self.is_F_diagonal:
             raise NotImplementedError('If the MOGP kernel covariance is not diagonal, the Sobol error calculation is unstable.')   # :380-381
-        if self.is_gp_covariant:
-            raise NotImplementedError('Sobol errors of a covariant GP (psi_factor on the (LN) Cholesky factor) are not built on this backend')
         M = self.M
         self._W_diag: Dict[Tuple[int, int], np.ndarray] = {}
         self._W_mixed: Dict[Tuple[int, int], np.ndarray] = {}

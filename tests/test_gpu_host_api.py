@@ -205,6 +205,21 @@ def test_covariant_gp_end_to_end(gpu, tmp_path):
     lit = mo.sobol_V_covariant(gp.X, KiY, F, ell, slices)
     got = full.marginalize_all(slices)['V']
     np.testing.assert_allclose(np.moveaxis(got, -1, 0), lit, rtol=1e-7, atol=1e-10 * np.max(np.abs(lit)))
+    # standard errors on the covariant GP (F diagonal): psi_factor solves with the (LN) Cholesky factor, the vector embedded in its
+    # output block (gsa/calibrators.py:304-308) -- against the literal transliteration
+    from oracle.sobol_error_oracle import LiteralClosedSobolWithError
+    Kc = mo.k_cho(gp.X, ell, F, Sigma)
+    for partial in (True, False):
+        err = LiteralClosedSobolWithError(gp.X, KiY, np.diag(F)[None, :], ell, Kc, is_T_partial=partial)
+        sobol = Sobol(gp, GSA.Kind.FIRST_ORDER, is_error_calculated=True, is_T_partial=partial)
+        sobol.calibrate()
+        per_slice = [err.marginalize(sl) for sl in o.gsa_slices(o.FIRST_ORDER, 3)]
+        W = np.stack([r['W'] for r in per_slice], axis=-1)
+        T = np.stack([r['T'] for r in per_slice], axis=-1)
+        if not partial:
+            T = np.concatenate([T, err.T[..., None]], axis=-1)
+        np.testing.assert_allclose(sobol.results['W'], W, rtol=1e-5, atol=1e-6 * np.max(np.abs(W)))
+        np.testing.assert_allclose(sobol.results['T'], T, rtol=1e-4, atol=1e-3 * np.max(np.abs(T)))
     gp.close()
     gsa_names = run.gsa('gpr', repo, is_covariant=True, is_isotropic=False, kinds=GSA.Kind.FIRST_ORDER)
     assert [str(n) for n in gsa_names] == ['gpr.c.a/gsa/first_order']

@@ -158,3 +158,20 @@ def test_predict_gradient_mean_is_the_gradient_of_the_posterior_mean():
     m1, v1 = mo.predict_gradient(X, Y, ell, F, S, xs)
     m0, v0 = go.predict_gradient(X, Y[:, 0], ell[0], F[0, 0], S[0, 0], xs)
     assert np.allclose(m1[:, 0, :], m0, rtol=1e-11, atol=1e-13) and np.allclose(v1[:, 0, :, 0], v0, rtol=1e-9, atol=1e-12)
+
+
+def test_sobol_errors_rank2_cholesky_branch_reduces_to_the_independent_case():
+    """psi_factor with the (LN, LN) factor of a covariant GP (gsa/calibrators.py:304-308): for a block-diagonal system it must give
+    what the (L, N, N) branch gives."""
+    from oracle.sobol_error_oracle import LiteralClosedSobolWithError
+    rng = np.random.default_rng(0)
+    N, M, L = 14, 3, 2
+    X, Y, ell = rng.standard_normal((N, M)), rng.standard_normal((N, L)), 0.8 + rng.random((L, M))
+    F, S = np.diag([1.3, 0.7]), np.diag([0.05, 0.08])
+    KiY, Kc = mo.k_inv_y(X, Y, ell, F, S), mo.k_cho(X, ell, F, S)
+    Kc3 = np.stack([go.k_cho(X, ell[l], F[l, l], S[l, l]) for l in range(L)])
+    a = LiteralClosedSobolWithError(X, KiY, np.diag(F)[None, :], ell, Kc, is_T_partial=False)
+    b = LiteralClosedSobolWithError(X, KiY, np.diag(F)[None, :], ell, Kc3, is_T_partial=False)
+    for sl in ((0, 2), (1, 2), (2, 3)):
+        ra, rb = a.marginalize(sl), b.marginalize(sl)
+        assert np.allclose(ra['W'], rb['W'], rtol=1e-9, atol=1e-14) and np.allclose(ra['T'], rb['T'], rtol=1e-6, atol=1e-12)
