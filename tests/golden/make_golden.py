@@ -57,8 +57,36 @@ def multi_output_case(N=40, M=4, L=2):
              V0=lit.V[0], S=lit.S)
 
 
+def covariant_case(N=90, M=3, L=2):
+    """One covariant GP (romcomma.gpf): LML, gradients, K_inv_Y, predict, gradient GP, Sobol V with the full and the diagonal F."""
+    from oracle import mogp_oracle as mo
+    X, _ = o.synthetic_fold(N, M, k=5)
+    Y = np.stack([o.synthetic_fold(N, M, k=5, l=l)[1] for l in range(L)], axis=1)
+    rng = np.random.Generator(np.random.PCG64(7))
+    ell = rng.uniform(0.6, 2.5, (L, M))
+    C = np.tril(rng.uniform(-0.4, 0.4, (L, L)), -1) + np.diag(rng.uniform(0.8, 1.4, L))
+    Cn = np.tril(rng.uniform(-0.03, 0.03, (L, L)), -1) + np.diag(rng.uniform(0.1, 0.2, L))
+    F, Sigma = C @ C.T, Cn @ Cn.T
+    F, Sigma = (F + F.T) / 2, (Sigma + Sigma.T) / 2
+    Xs, _ = o.synthetic_fold(12, M, k=55)
+    lml, dF, dell, dS = mo.lml_and_grad(X, Y, ell, F, Sigma)
+    KiY = mo.k_inv_y(X, Y, ell, F, Sigma)
+    mean_y, sd_y = mo.predict(X, Y, ell, F, Sigma, Xs, True)
+    mean_f, sd_f = mo.predict(X, Y, ell, F, Sigma, Xs, False)
+    gmean, gvar = mo.predict_gradient(X, Y, ell, F, Sigma, Xs[:3])
+    slices = np.array(o.all_slices(M) + [(M, M)], dtype=np.int32)
+    V_full = mo.sobol_V_covariant(X, KiY, F, ell, slices)
+    cal = o.ClosedSobolOracle(X, KiY, np.diag(F)[None, :], ell)
+    V_diag = np.stack([cal.marginalize(s)['V'] for s in slices])
+    Lc = mo.k_cho(X, ell, F, Sigma)
+    np.savez(HERE / f'mogp_N{N}_M{M}_L{L}.npz', X=X, Y=Y, ell=ell, F=F, Sigma=Sigma, Xs=Xs, lml=lml, dF=dF, dell=dell, dSigma=dS, K_inv_Y=KiY,
+             K_cho_diag=np.diag(Lc).copy(), K_cho_checksum=float(np.sum(Lc)), mean_y=mean_y, sd_y=sd_y, mean_f=mean_f, sd_f=sd_f,
+             gmean=gmean, gvar=gvar, slices=slices, V_full=V_full, V_diag=V_diag)
+
+
 if __name__ == '__main__':
     for N, M, seed in [(16, 1, 0), (64, 3, 1), (256, 10, 2), (300, 7, 3)]:
         case(N, M, seed)
     multi_output_case()
+    covariant_case()
     print('wrote', sorted(p.name for p in HERE.glob('*.npz')))

@@ -170,3 +170,31 @@ def test_predict_gradient():
         gp.set_hyper(ell, F, S)
         with pytest.raises(_lib.RcgpError):
             gp.predict_gradient(np.zeros((700, 3)))                       # L n M > 4096
+
+
+def test_covariant_golden_fixture():
+    """Every quantity of tests/golden/mogp_N90_M3_L2.npz through the C ABI (the oracle is not imported here)."""
+    from pathlib import Path
+    from romcomma_amd import _lib
+    from romcomma_amd.gsa.calibrators import covariant_V
+    g = np.load(Path(__file__).resolve().parent / 'golden' / 'mogp_N90_M3_L2.npz')
+    X, Y, ell, F, S = g['X'], g['Y'], g['ell'], g['F'], g['Sigma']
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, S)
+        lml, gF, gell, gS = gp.lml_grad()
+        assert lml == pytest.approx(float(g['lml']), rel=1e-11)
+        for got, ref in ((gF, g['dF']), (gell, g['dell']), (gS, g['dSigma'])):
+            assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
+        KiY = gp.k_inv_y()
+        assert np.allclose(KiY, g['K_inv_Y'], rtol=1e-8, atol=1e-10)
+        Lc = gp.k_cho()
+        assert np.allclose(np.diag(Lc), g['K_cho_diag'], rtol=1e-10) and np.sum(Lc) == pytest.approx(float(g['K_cho_checksum']), rel=1e-10)
+        for flag, mk, sk in ((True, 'mean_y', 'sd_y'), (False, 'mean_f', 'sd_f')):
+            mean, sd = gp.predict(g['Xs'], flag)
+            assert np.allclose(mean, g[mk], rtol=1e-9, atol=1e-10) and np.allclose(sd, g[sk], rtol=1e-8)
+        m_lom, cov = gp.predict_gradient(g['Xs'][:3])
+        assert np.allclose(np.transpose(m_lom, (1, 0, 2)), g['gmean'], rtol=1e-8, atol=1e-10)
+        Vf = covariant_V(gp, g['K_inv_Y'], F, ell, g['slices'])
+        Vd = covariant_V(gp, g['K_inv_Y'], np.diag(F), ell, g['slices'], is_F_diagonal=True)
+    assert np.allclose(Vf, g['V_full'], rtol=1e-8, atol=1e-11 * np.abs(g['V_full']).max())
+    assert np.allclose(Vd, g['V_diag'], rtol=1e-8, atol=1e-11 * np.abs(g['V_diag']).max())

@@ -175,3 +175,17 @@ def test_sobol_errors_rank2_cholesky_branch_reduces_to_the_independent_case():
     for sl in ((0, 2), (1, 2), (2, 3)):
         ra, rb = a.marginalize(sl), b.marginalize(sl)
         assert np.allclose(ra['W'], rb['W'], rtol=1e-9, atol=1e-14) and np.allclose(ra['T'], rb['T'], rtol=1e-6, atol=1e-12)
+
+
+def test_oracle_reproduces_the_covariant_golden_fixture():
+    """tests/golden/mogp_*.npz (made by tests/golden/make_golden.py from this oracle) pins the oracle against regressions."""
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / 'golden' / 'mogp_N90_M3_L2.npz')
+    X, Y, ell, F, S = g['X'], g['Y'], g['ell'], g['F'], g['Sigma']
+    v, dF, dell, dS = mo.lml_and_grad(X, Y, ell, F, S)
+    assert v == pytest.approx(float(g['lml']), rel=1e-12)
+    assert np.allclose(dF, g['dF'], rtol=1e-9) and np.allclose(dell, g['dell'], rtol=1e-9) and np.allclose(dS, g['dSigma'], rtol=1e-9)
+    assert np.allclose(mo.k_inv_y(X, Y, ell, F, S), g['K_inv_Y'], rtol=1e-9, atol=1e-12)
+    mean, sd = mo.predict(X, Y, ell, F, S, g['Xs'])
+    assert np.allclose(mean, g['mean_y'], rtol=1e-10, atol=1e-12) and np.allclose(sd, g['sd_y'], rtol=1e-10)
+    assert np.allclose(mo.sobol_V_covariant(X, g['K_inv_Y'], F, ell, g['slices']), g['V_full'], rtol=1e-10, atol=1e-15)
