@@ -224,3 +224,55 @@ def test_covariant_gp_end_to_end(gpu, tmp_path):
     gsa_names = run.gsa('gpr', repo, is_covariant=True, is_isotropic=False, kinds=GSA.Kind.FIRST_ORDER)
     assert [str(n) for n in gsa_names] == ['gpr.c.a/gsa/first_order']
     assert (repo.folder / 'gpr.c.a' / 'gsa' / 'first_order' / 'S.csv').exists()
+
+
+def test_covariant_gp_with_trained_kernel_covariance_and_lengthscales(gpu, tmp_path):
+    """Options as the reference takes them (kernel={'covariance': True, 'lengthscales': {'covariant': True}}): every parameter group of
+    the covariant GP trains, meta.json records it, and GSA then takes the non-diagonal-F branch on its own (gsa/calibrators.py:129-138).
+    Isotropic covariant model: (L,1) lengthscales."""
+    from oracle import mogp_oracle as mo
+    from romcomma_amd.data.storage import Fold
+    from romcomma_amd.gpr.models import MOGP
+    from romcomma_amd.gsa.calibrators import ClosedSobol
+    from romcomma_amd.gsa.models import GSA, Sobol
+    from romcomma_amd.user import run
+    repo = make_repo(tmp_path / 'repo', N=160, M=3, L=2, seed=8).into_K_folds(-2, seed=9)
+    fold = Fold(repo, 0)
+    run.gpr('gpr', fold, is_read=False, is_covariant=False, is_isotropic=False)
+    names = run.gpr('gpr', fold, is_read=None, is_covariant=True, is_isotropic=False,
+                    kernel={'covariance': True, 'lengthscales': {'covariant': True}})
+    assert names == ['gpr.c.a']
+    meta = json.loads((fold.folder / 'gpr.c.a' / 'meta.json').read_text())
+    assert meta['kernel']['covariance'] is True and meta['kernel']['lengthscales']['covariant'] is True
+    v = MOGP('gpr.v.a', fold, True, False, False)
+    ell_v = v.kernel.data.frames.lengthscales.np.copy()
+    lml_v = float(np.sum(v.likelihood.data.frames.log_marginal.np))
+    v.close()
+    gp = MOGP('gpr.c.a', fold, True, True, False)
+    ell, F = gp.kernel.data.frames.lengthscales.np, gp.kernel.data.frames.variance.np
+    assert F[0, 1] != 0.0 and F[0, 1] == pytest.approx(F[1, 0], rel=1e-12) and not np.array_equal(ell, ell_v)
+    assert float(gp.likelihood.data.frames.log_marginal.np[0, 0]) >= lml_v - 1e-6 * abs(lml_v)
+    Sigma = np.diag(np.diag(gp.likelihood.data.frames.variance.np))
+    Fs = (F + F.T) / 2
+    assert gp.log_marginal_likelihood()[0] == pytest.approx(mo.lml(gp.X, gp.Y, ell, Fs, Sigma), rel=1e-9)
+    cal = ClosedSobol(gp)                                                      # is_F_diagonal from meta.json: False
+    assert cal.is_F_diagonal is False
+    KiY = mo.k_inv_y(gp.X, gp.Y, ell, Fs, Sigma)
+    slices = [(0, 3), (0, 1), (1, 2), (2, 3)]
+    ref = mo.sobol_V_covariant(gp.X, KiY, Fs, ell, slices)
+    np.testing.assert_allclose(np.moveaxis(cal.marginalize_all(slices)['V'], -1, 0), ref, rtol=1e-6, atol=1e-9 * np.max(np.abs(ref)))
+    sobol = Sobol(gp, GSA.Kind.TOTAL)
+    sobol.calibrate()
+    assert sobol.results['S'].shape == (2, 2, 4)
+    with pytest.raises(NotImplementedError):                                   # errors need a diagonal F (gsa/calibrators.py:380-381)
+        Sobol(gp, GSA.Kind.TOTAL, is_error_calculated=True).calibrate()
+    gp.close()
+    # isotropic covariant model from scratch
+    names = run.gpr('iso', fold, is_read=False, is_covariant=True, is_isotropic=True, kernel={'lengthscales': {'covariant': True}})
+    assert names == ['iso.c.i']
+    iso = MOGP('iso.c.i', fold, True, True, True)
+    assert iso.kernel.data.frames.lengthscales.np.shape == (2, 1) and iso.kernel.data.frames.variance.np.shape == (2, 2)
+    ell_i = np.broadcast_to(iso.kernel.data.frames.lengthscales.np, (2, 3))
+    Sigma_i = np.diag(np.diag(iso.likelihood.data.frames.variance.np))
+    assert iso.log_marginal_likelihood()[0] == pytest.approx(mo.lml(iso.X, iso.Y, ell_i, iso.kernel.data.frames.variance.np, Sigma_i), rel=1e-9)
+    iso.close()

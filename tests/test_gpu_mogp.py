@@ -198,3 +198,18 @@ def test_covariant_golden_fixture():
         Vd = covariant_V(gp, g['K_inv_Y'], np.diag(F), ell, g['slices'], is_F_diagonal=True)
     assert np.allclose(Vf, g['V_full'], rtol=1e-8, atol=1e-11 * np.abs(g['V_full']).max())
     assert np.allclose(Vd, g['V_diag'], rtol=1e-8, atol=1e-11 * np.abs(g['V_diag']).max())
+
+
+def test_many_input_dimensions():
+    """M > 32 takes the wide-LDS instantiation of the gradient kernel (k_grad_mo<65>)."""
+    from oracle import mogp_oracle as mo
+    from romcomma_amd import _lib
+    X, Y, ell, F, S = _case(150, 40, 2, seed=23)
+    ell = ell * 6.0
+    v, dF, dell, dS = mo.lml_and_grad(X, Y, ell, F, S)
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, S)
+        lml, gF, gell, gS = gp.lml_grad()
+    assert lml == pytest.approx(v, rel=1e-10)
+    for got, ref in ((gF, dF), (gell, dell), (gS, dS)):
+        assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
