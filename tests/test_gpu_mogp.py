@@ -213,3 +213,59 @@ def test_many_input_dimensions():
     assert lml == pytest.approx(v, rel=1e-10)
     for got, ref in ((gF, dF), (gell, dell), (gS, dS)):
         assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
+
+
+def test_full_size_properties():
+    """L N = 16384 (two outputs of N = 8192, M = 10), where the oracle is out of reach: size-independent properties.
+    (1) With diagonal F and Sigma the joint system is block diagonal: LML, gradients and K_inv_Y must be those of the two independent
+    GPs (computed through the single-output entry points). (2) Swapping the outputs (with their lengthscales, and F, Sigma permuted)
+    leaves the LML unchanged and permutes the gradients. (3) check_K_inv_Y: k(x, X) . K_inv_Y reproduces predict_f."""
+    from romcomma_amd import _lib
+    from romcomma_amd.user.sample import bench_hyper, synthetic_fold
+    N, M, L = 8192, 10, 2
+    X, y0 = synthetic_fold(N, M)
+    Y = np.stack([y0, synthetic_fold(N, M, l=1)[1]], axis=1)
+    ell0, var, noise = bench_hyper(M)
+    ell = np.stack([ell0, 1.15 * ell0])
+    Fd, Sd = np.diag([var, 0.8 * var]), np.diag([noise, 1.7 * noise])
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, Fd, Sd)
+        lml, gF, gell, gS = gp.lml_grad()
+        alpha = gp.k_inv_y()
+        parts = []
+        for l in range(L):
+            with _lib.RcGP(X, Y[:, l]) as one:
+                one.set_hyper(ell[l], Fd[l, l], Sd[l, l])
+                v, g = one.lml_grad()
+                parts.append((v, g, one.k_inv_y()))
+        assert lml == pytest.approx(parts[0][0] + parts[1][0], rel=1e-11)
+        for l in range(L):
+            assert np.allclose(gell[l], parts[l][1][:M], rtol=1e-8, atol=1e-8 * np.abs(parts[l][1][:M]).max())
+            assert gF[l, l] == pytest.approx(parts[l][1][M], rel=1e-8) and gS[l, l] == pytest.approx(parts[l][1][M + 1], rel=1e-8)
+            assert np.allclose(alpha[l, 0], parts[l][2], rtol=1e-7, atol=1e-9 * np.abs(parts[l][2]).max())
+        # (2) a genuinely covariant setting and its output-swapped twin
+        C = np.array([[1.0, 0.0], [0.45, 0.8]])
+        Cn = np.array([[0.04, 0.0], [0.01, 0.05]])
+        F, S = var * C @ C.T, Cn @ Cn.T
+        F, S = (F + F.T) / 2, (S + S.T) / 2
+        gp.set_hyper(ell, F, S)
+        lml_a, gF_a, gell_a, gS_a = gp.lml_grad()
+        Xs = synthetic_fold(64, M, k=9)[0]
+        mean_f, _ = gp.predict(Xs, False)
+        KiY = gp.k_inv_y()[:, 0, :]
+        u = Xs[None, :, :] / ell[:, None, :]
+        U = X[None, :, :] / ell[:, None, :]
+        recon = np.zeros((64, L))
+        for l in range(L):
+            for j in range(L):
+                r2 = np.sum(u[l] ** 2, 1)[:, None] + np.sum(U[j] ** 2, 1)[None, :] - 2.0 * u[l] @ U[j].T
+                recon[:, l] += F[l, j] * np.exp(-0.5 * r2) @ KiY[j]
+        assert np.abs(recon - mean_f).max() <= 1e-7 * max(1.0, np.abs(mean_f).max())
+    P = [1, 0]
+    with _lib.RcMOGP(X, Y[:, P]) as gp:
+        gp.set_hyper(ell[P], F[np.ix_(P, P)], S[np.ix_(P, P)])
+        lml_b, gF_b, gell_b, gS_b = gp.lml_grad()
+    assert lml_b == pytest.approx(lml_a, rel=1e-10)
+    assert np.allclose(gell_b, gell_a[P], rtol=1e-6, atol=1e-7 * np.abs(gell_a).max())
+    assert np.allclose(gF_b, gF_a[np.ix_(P, P)], rtol=1e-6, atol=1e-7 * np.abs(gF_a).max())
+    assert np.allclose(gS_b, gS_a[np.ix_(P, P)], rtol=1e-6, atol=1e-7 * np.abs(gS_a).max())
