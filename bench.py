@@ -150,6 +150,18 @@ def main():
     prof = {name: gp.profile_get(c) for c, name in enumerate(_lib.KERNEL_CLASS_NAMES)}
     gp.set_profiling(False)
 
+    # Outside the timed region: the blocked Cholesky on its own at the fitted hyper-parameters (north_star quotes its MFMA fraction).
+    # Inside a fit it cannot be timed separately: its kernels overlap on several streams.
+    chol_ms = []
+    if rank == 0:
+        for _ in range(3):
+            gp.stage_gram()
+            gp.sync()
+            t1 = time.perf_counter()
+            gp.stage_potrf()
+            gp.sync()
+            chol_ms.append(1e3 * (time.perf_counter() - t1))
+
     if rank == 0:
         n_gemm, ms_gemm, flops = prof['gemm']
         n_grad, ms_grad, grad_flops = prof['grad']
@@ -182,6 +194,9 @@ def main():
                 'gram': {'bound': 'hbm', 'achieved_GBs': gram_bytes / (ms_gram * 1e-3) / 1e9 if ms_gram > 0 else 0.0, 'peak_GBs': HBM_PEAK_GBS,
                          'frac': (gram_bytes / (ms_gram * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_gram > 0 else 0.0,
                          'launches': int(n_gram), 'avg_launch_ms': ms_gram / max(n_gram, 1)},
+                'cholesky': {'bound': 'mfma', 'algorithmic_flops': N ** 3 / 3.0, 'ms': min(chol_ms), 'achieved_TFLOPs': N ** 3 / 3.0 / (min(chol_ms) * 1e-3) / 1e12,
+                             'frac': N ** 3 / 3.0 / (min(chol_ms) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                             'note': 'stand-alone rcgp_stage_potrf (incl. w = L^-1 y) after the timed region, best of 3, host wall clock around a sync'},
                 'diag_blocks': {'launches': int(n_diag), 'total_ms': ms_diag},
                 'sobol': {'launches': int(n_sob), 'total_ms': ms_sob, 'Gexp_per_s': sob_exps / (ms_sob * 1e-3) / 1e9 if ms_sob > 0 else 0.0},
                 'mfma_gemm_family': {'launches': int(n_gemm + n_grad), 'summed_launch_ms': ms_gemm + ms_grad,

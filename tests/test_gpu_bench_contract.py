@@ -29,5 +29,7 @@ def test_bench_json_contract(gpu):
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
     assert r['frac'] == pytest.approx(r['achieved'] / r['peak'], rel=1e-12) and r['achieved'] > 0
     assert 'traffic' in r                                    # None away from the profiled C2 size
+    ch = d['stages']['cholesky']
+    assert ch['ms'] > 0 and ch['frac'] == pytest.approx(ch['achieved_TFLOPs'] / r['peak'], rel=1e-12)
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == d['unit'] and c['sample']
