@@ -400,3 +400,49 @@ def test_sobol_error_terms_many_dimensions(gpu):
     with pytest.raises(gpu.RcgpError, match='at most 29'):
         gp.sobol_error_terms([(0, 1)])
     gp.close()
+
+
+def test_multi_stream_cholesky_is_bitwise_reproducible(gpu):
+    """The look-ahead factorisation runs on six streams ordered by events only. Every tile is written by kernels in one fixed order,
+    so repeated factorisations must agree BIT FOR BIT; a missing dependency would show up here as run-to-run differences."""
+    from romcomma_amd import _lib
+    for N, M in ((3000, 4), (5200, 6)):
+        X, y = o.synthetic_fold(N, M, k=7)
+        ell, var, noise = o.bench_hyper(M)
+        with _lib.RcGP(X, y) as gp:
+            gp.set_hyper(ell, var, noise)
+            first = None
+            for rep in range(12):
+                gp.stage_gram()
+                gp.stage_potrf()
+                gp.sync()
+                Lc = gp.k_cho()                      # the factor is cached: no refactorisation here
+                lml = gp.lml()
+                if first is None:
+                    first = (Lc, lml)
+                else:
+                    assert lml == first[1]
+                    assert np.array_equal(Lc, first[0])
+            _, g0 = gp.lml_grad()
+            gp.stage_gram()
+            _, g1 = gp.lml_grad()
+            assert np.array_equal(g0, g1)
+
+
+def test_full_size_evaluation_is_bitwise_reproducible(gpu):
+    """The same at C2 size through quantities that depend on every entry of the factor: LML, gradient, K_inv_Y."""
+    from romcomma_amd import _lib
+    N, M = 16384, 10
+    X, y = o.synthetic_fold(N, M)
+    ell, var, noise = o.bench_hyper(M)
+    with _lib.RcGP(X, y) as gp:
+        gp.set_hyper(ell, var, noise)
+        ref = None
+        for rep in range(5):
+            gp.stage_gram()                                 # invalidates the cached factor
+            lml, grad = gp.lml_grad()
+            alpha = gp.k_inv_y()
+            if ref is None:
+                ref = (lml, grad, alpha)
+            else:
+                assert lml == ref[0] and np.array_equal(grad, ref[1]) and np.array_equal(alpha, ref[2])
