@@ -354,20 +354,39 @@ __global__ void __launch_bounds__(64 * NW) k_prep1(double* T, int64_t ld, const 
   double* red = wv + 128;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
   const int r0 = 16 * blockIdx.x;
-  for (int e = t; e < 128 * 64; e += 64 * NW) {         // rows of inv below the strip's reach are never used: j < 128 always needed
-    const int i = e >> 6, j2 = (e & 63) * 2;
-    double2 v = make_double2(0.0, 0.0);
-    if (j2 <= i) v = *reinterpret_cast<const double2*>(invL + i * 128 + j2);
-    Inv[i * LP + j2] = v.x;
-    Inv[i * LP + j2 + 1] = v.y;
+  // Every global load of the kernel is issued before the first one is waited for: left as a loop the compiler emits load - wait -
+  // LDS store per iteration, i.e. 16-32 memory round trips in a row, and under the bulk update's traffic one round trip takes
+  // microseconds (this kernel went from 10 to 30-280 us beside a window piece).
+  constexpr int NLI = 128 * 64 / (64 * NW), NLT = (16 * 64 + 64 * NW - 1) / (64 * NW);
+  double2 vi[NLI], vt[NLT];
+#pragma unroll
+  for (int q = 0; q < NLI; ++q) {
+    const int e = t + 64 * NW * q, i = e >> 6, j2 = (e & 63) * 2;
+    vi[q] = make_double2(0.0, 0.0);
+    if (j2 <= i) vi[q] = *reinterpret_cast<const double2*>(invL + i * 128 + j2);
   }
-  for (int e = t; e < 16 * 64; e += 64 * NW) {
-    const int i = e >> 6, j2 = (e & 63) * 2;
-    const double2 v = *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2);
-    Ts[i * LP + j2] = v.x;
-    Ts[i * LP + j2 + 1] = v.y;
+#pragma unroll
+  for (int q = 0; q < NLT; ++q) {
+    const int e = t + 64 * NW * q, i = e >> 6, j2 = (e & 63) * 2;
+    vt[q] = make_double2(0.0, 0.0);
+    if (e < 16 * 64) vt[q] = *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2);
   }
-  if (t < 128) wv[t] = wj[t];
+  const double wreg = (t < 128) ? wj[t] : 0.0;
+#pragma unroll
+  for (int q = 0; q < NLI; ++q) {
+    const int e = t + 64 * NW * q, i = e >> 6, j2 = (e & 63) * 2;
+    Inv[i * LP + j2] = vi[q].x;
+    Inv[i * LP + j2 + 1] = vi[q].y;
+  }
+#pragma unroll
+  for (int q = 0; q < NLT; ++q) {
+    const int e = t + 64 * NW * q, i = e >> 6, j2 = (e & 63) * 2;
+    if (e < 16 * 64) {
+      Ts[i * LP + j2] = vt[q].x;
+      Ts[i * LP + j2 + 1] = vt[q].y;
+    }
+  }
+  if (t < 128) wv[t] = wreg;
   __syncthreads();
   double part[4] = {0.0, 0.0, 0.0, 0.0};           // this wave's share of (strip row fq + 4q) . wj
 #pragma unroll
@@ -416,14 +435,20 @@ __global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, do
   int bi = 0, rem = blockIdx.x;                     // lower 32x32 blocks of the 4x4 block grid, row by row
   while (rem > bi) { rem -= bi + 1; ++bi; }
   const int bj = rem;
-  for (int e = t; e < 32 * 64; e += 256) {
-    const int i = e >> 6, j2 = (e & 63) * 2;
-    const double2 va = *reinterpret_cast<const double2*>(Lt + (int64_t)(32 * bi + i) * ld + j2);
-    const double2 vb = *reinterpret_cast<const double2*>(Lt + (int64_t)(32 * bj + i) * ld + j2);
-    La[i * LP + j2] = va.x;
-    La[i * LP + j2 + 1] = va.y;
-    Lb[i * LP + j2] = vb.x;
-    Lb[i * LP + j2 + 1] = vb.y;
+  double2 va[8], vb[8];                             // all 16 loads in flight together (see k_prep1)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
+    va[q] = *reinterpret_cast<const double2*>(Lt + (int64_t)(32 * bi + i) * ld + j2);
+    vb[q] = *reinterpret_cast<const double2*>(Lt + (int64_t)(32 * bj + i) * ld + j2);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
+    La[i * LP + j2] = va[q].x;
+    La[i * LP + j2 + 1] = va[q].y;
+    Lb[i * LP + j2] = vb[q].x;
+    Lb[i * LP + j2 + 1] = vb[q].y;
   }
   const int ti = wave >> 1, tj = wave & 1;
   double* Dt = D + (int64_t)(32 * bi + 16 * ti) * ld + 32 * bj + 16 * tj;
