@@ -7,7 +7,8 @@ One step = one pass of the hot path over one synthetic fold resident in HBM: L-B
 reference's default start (ell 5.0, variance 2.0, noise 0.02; gpr/kernels.py:49-50, gpr/models.py:52) with the reference's
 optimiser options (maxiter 5000, gtol 1e-16; gpr/models.py:327-330) to convergence, then the closed-form first-order /
 closed / total Sobol indices (3M+1 quadratic forms), then the gather of every rank's indices (RCCL when N > 1).
-Weak scaling: rank r owns fold r of an 8-fold split of one seeded dataset (every fold trains on N rows); value = ranks * N *
+Weak scaling: timed step s of rank r fits fold (r + s) mod 8 of an 8-fold split of one seeded dataset (every fold trains on N
+rows, all folds a rank meets are resident in HBM beforehand); value = ranks * N *
 steps / max-over-ranks wall time.
 Prints ONE JSON line on rank 0.
 """
@@ -90,7 +91,7 @@ def main():
     ap.add_argument('--dims', dest='m', type=int, default=10, help='input dimensions (BASELINE configs[2]: 10)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shard', choices=('folds', 'outputs'), default='folds',
-                    help="what a rank owns: fold r of an 8-fold split (default, BASELINE configs[4] style) or output column r on a shared "
+                    help="what a rank owns: folds of an 8-fold split, (r + step) mod 8 (default, BASELINE configs[4] style), or output column r on a shared "
                          "design (configs[3] style)")
     ap.add_argument('--profile-steps', choices=('all', 'last', 'none'), default='last',
                     help='timed steps whose kernel launches carry HIP events (the roofline figures come from those launches)')
@@ -111,17 +112,33 @@ def main():
         raise SystemExit('bench.py needs a GPU: librcgp has no CPU fallback')
 
     N, M = args.n, args.m
-    K_folds = max(8, world)                          # fold r of a K-fold split of one seeded dataset: every fold trains on N rows
+    K_folds = max(8, world)                          # folds of a K-fold split of one seeded dataset: every fold trains on N rows
+    n_steps_total = args.warmup + args.steps
     if args.shard == 'outputs':                      # the same design on every rank, output column r
         X, Y = synthetic_outputs(N, M, max(8, world))
-        y = Y[:, rank]
+        units = [rank] * n_steps_total
+        handles = {rank: _lib.RcGP(X, Y[:, rank], device=local_rank)}
     else:
-        X, y = synthetic_cv_fold(N, M, k=rank, K=K_folds)
-    gp = _lib.RcGP(X, y, device=local_rank)         # inputs resident in HBM from here on
+        # Timed step s of rank r fits fold (r + s) mod K: a K-fold cross-validation handed round the GPUs, so that over the steps every
+        # rank meets the cheap and the expensive folds alike (the folds' fits take 71-86 L-BFGS-B evaluations at C2) and one step
+        # still is one fold per GPU. Every fold this rank will meet is resident in HBM before the timed region starts.
+        # (Warm-up steps take the folds before r, so that timed step s is fold r + s.)
+        units = [(rank - args.warmup + s) % K_folds for s in range(n_steps_total)]
+        handles = {}
+        for k in dict.fromkeys(units):
+            Xk, yk = synthetic_cv_fold(N, M, k=k, K=K_folds)
+            handles[k] = _lib.RcGP(Xk, yk, device=local_rank)
+            handles[k].set_hyper(4.0 * np.ones(M), 1.5, 0.03)          # one evaluation per handle, NOT at the fit's start point (an
+            handles[k].lml_grad()                                       # unchanged point would let the first timed evaluation reuse the
+                                                                        # factor): its work buffers (L^-1, scratch) exist before the timed region
     slices = all_slices(M)
     last = {}
+    counter = {'s': 0}
+    gp = handles[units[-1]]                          # the handle of the last timed step: profiled launches, stand-alone stages
 
     def step(profiled=False):
+        gp = handles[units[counter['s']]]
+        counter['s'] += 1
         fit = fit_lbfgsb(gp, 5.0 * np.ones(M), 2.0, 0.02)
         if profiled:
             gp.set_profiling(True)
@@ -132,23 +149,30 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    gp.profile_reset()
-    gp.sync()
+    for h in handles.values():
+        h.profile_reset()
+        h.sync()
     dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         # Per-launch HIP events cost ~5 % (profiled dispatches, marker packets on the panel chain, harvesting), so by default
         # they are a SAMPLE of the timed region: the last step, every --profile-every-th evaluation of its fit, and its Sobol pass.
         profiled = args.profile_steps == 'all' or (args.profile_steps == 'last' and i == args.steps - 1)
-        gp.profile_sample(args.profile_every if profiled else 0)
-        gp.set_profiling(False)
+        cur = handles[units[counter['s']]]
+        cur.profile_sample(args.profile_every if profiled else 0)
+        cur.set_profiling(False)
         step(profiled)
-    gp.sync()
+    for h in handles.values():
+        h.sync()
     dist.barrier()
     elapsed = dist.max_over_ranks(time.perf_counter() - t0)
-    gp.profile_sample(0)
-    prof = {name: gp.profile_get(c) for c, name in enumerate(_lib.KERNEL_CLASS_NAMES)}
-    gp.set_profiling(False)
+    prof = {}
+    for h in handles.values():                       # launches carry HIP events on the handle of the profiled step(s) only
+        h.profile_sample(0)
+        for c, name in enumerate(_lib.KERNEL_CLASS_NAMES):
+            got = h.profile_get(c)
+            prof[name] = tuple(a + b for a, b in zip(prof.get(name, (0, 0.0, 0.0)), got))
+        h.set_profiling(False)
 
     # Outside the timed region: the blocked Cholesky on its own at the fitted hyper-parameters (north_star quotes its MFMA fraction).
     # Inside a fit it cannot be timed separately: its kernels overlap on several streams.
@@ -181,7 +205,7 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'{"C2" if (N, M) == (16384, 10) else "custom"}: ARD-RBF GP fit (L-BFGS-B to convergence, reference defaults) + closed-form Sobol first/closed/'
-                                   f'total indices, N={N}, M={M}, ' + (f'L=1, fold r of an {K_folds}-fold split per GPU' if args.shard == 'folds' else
+                                   f'total indices, N={N}, M={M}, ' + (f'L=1, fold (r + step) mod {K_folds} of an {K_folds}-fold split on GPU r' if args.shard == 'folds' else
                                                           f'output r of {max(8, world)} independent outputs on one design per GPU'),
                        'N': N, 'M': M, 'lbfgs_evaluations_last_step': nfev, 'parallelism': f'{args.shard[:-1]}-per-gpu x{world}',
                        'log_marginal': last['fit']['log_marginal']},
@@ -208,7 +232,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(N, M, nfev)
         print(json.dumps(out), flush=True)
-    gp.close()
+    for h in handles.values():
+        h.close()
     if dist.is_distributed():
         import torch.distributed as td
         td.destroy_process_group()

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 
 #define RC_API extern "C" __attribute__((visibility("default")))
 #define RC_CHECK_H(h)            \
@@ -21,6 +23,33 @@ RC_API int rcgp_device_count(void) {
   return n;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One set of streams per device, shared by every handle of the process on that device (reference-counted). Every stream is a
+// hardware queue that the runtime keeps for the life of the process, and the multi-stream Cholesky slows down by a quarter
+// once a few more queues than its own six exist (three handles alive at once: 34 -> 43 ms at C2; DESIGN.md "tried and
+// rejected"). Handles are used one call at a time by their owner, so sharing the streams only orders the work of different
+// handles of one device behind each other. The tuning knobs that shape the streams are read when the set is created.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RcDeviceStreams {
+  hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr, stream5 = nullptr, stream6 = nullptr;
+  int refs = 0;
+};
+static std::mutex g_streams_mutex;
+static std::map<int, RcDeviceStreams> g_streams;
+
+static void release_streams(rcgp_handle_s* h) {
+  if (!h->streams_acquired) return;
+  std::lock_guard<std::mutex> lock(g_streams_mutex);
+  RcDeviceStreams& ds = g_streams[h->device];
+  if (--ds.refs == 0) {
+    hipStream_t* all[] = {&ds.stream4, &ds.stream6, &ds.stream5, &ds.stream3, &ds.stream2, &ds.stream};
+    for (auto sp : all)
+      if (*sp) { (void)hipStreamDestroy(*sp); *sp = nullptr; }
+  }
+  h->stream = h->stream2 = h->stream3 = h->stream4 = h->stream5 = h->stream6 = nullptr;
+  h->streams_acquired = false;
+}
+
 static void free_all(rcgp_handle_s* h) {
   double** bufs[] = {&h->X, &h->Z, &h->sq, &h->y, &h->w, &h->alpha, &h->A, &h->Linv, &h->S, &h->invdiag, &h->logdiag, &h->partial,
                      &h->scal, &h->ell_d, &h->FS_d, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob, &h->gV, &h->gC};
@@ -34,12 +63,7 @@ static void free_all(rcgp_handle_s* h) {
   for (auto& e : h->la_events) (void)hipEventDestroy(e);
   h->la_events.clear();
   if (h->ev_inv) { (void)hipEventDestroy(h->ev_inv); h->ev_inv = nullptr; }
-  if (h->stream4) { (void)hipStreamDestroy(h->stream4); h->stream4 = nullptr; }
-  if (h->stream6) { (void)hipStreamDestroy(h->stream6); h->stream6 = nullptr; }
-  if (h->stream5) { (void)hipStreamDestroy(h->stream5); h->stream5 = nullptr; }
-  if (h->stream3) { (void)hipStreamDestroy(h->stream3); h->stream3 = nullptr; }
-  if (h->stream2) { (void)hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
-  if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
+  release_streams(h);
 }
 
 static std::string g_create_error;
@@ -65,17 +89,14 @@ static int upload_targets(rcgp_handle_s* h, const double* Y) {
   return 0;
 }
 
-static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
-  const int64_t Np = h->Np;
-  const int M = h->M;
-  RC_HIP(hipSetDevice(h->device));
-  RC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
+  RC_HIP(hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking));
   {
     int lo = 0, hi = 0;
     RC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // hi is the numerically lowest = highest priority
-    RC_HIP(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
-    RC_HIP(hipStreamCreateWithPriority(&h->stream5, hipStreamNonBlocking, hi));
-    RC_HIP(hipStreamCreateWithPriority(&h->stream6, hipStreamNonBlocking, hi));
+    RC_HIP(hipStreamCreateWithPriority(&ds.stream2, hipStreamNonBlocking, hi));
+    RC_HIP(hipStreamCreateWithPriority(&ds.stream5, hipStreamNonBlocking, hi));
+    RC_HIP(hipStreamCreateWithPriority(&ds.stream6, hipStreamNonBlocking, hi));
   }
   {
     // The bulk-update stream may use every CU except the first RCGP_RESERVE_CUS, which stay free for the panel chain.
@@ -88,12 +109,12 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     for (int cu = 0; cu < ncu; ++cu)
       if (cu >= reserve) mask[cu / 32] |= (1u << (cu % 32));
     hipError_t me = hipErrorInvalidValue;
-    if (reserve > 0 && reserve < ncu) me = hipExtStreamCreateWithCUMask(&h->stream3, (uint32_t)mask.size(), mask.data());
+    if (reserve > 0 && reserve < ncu) me = hipExtStreamCreateWithCUMask(&ds.stream3, (uint32_t)mask.size(), mask.data());
     if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] %d CUs, reserve %d, CU-mask stream: %s\n", ncu, reserve, hipGetErrorString(me));
     if (me != hipSuccess) {
       (void)hipGetLastError();
-      RC_HIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-      RC_HIP(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
+      RC_HIP(hipStreamCreateWithFlags(&ds.stream3, hipStreamNonBlocking));
+      RC_HIP(hipStreamCreateWithFlags(&ds.stream4, hipStreamNonBlocking));
     } else {
       // the overlapped L^-1 kernels run long tiles: confine them to the upper part of the chip so that the panel chain's GEMMs
       // (which want many CUs at once) always find free ones
@@ -103,13 +124,32 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
       for (int cu = 0; cu < ncu; ++cu)
         if (cu >= reserve_inv) mask4[cu / 32] |= (1u << (cu % 32));
       if (reserve_inv <= 0 || reserve_inv >= ncu ||
-          hipExtStreamCreateWithCUMask(&h->stream4, (uint32_t)mask4.size(), mask4.data()) != hipSuccess) {
+          hipExtStreamCreateWithCUMask(&ds.stream4, (uint32_t)mask4.size(), mask4.data()) != hipSuccess) {
         (void)hipGetLastError();
-        RC_HIP(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
+        RC_HIP(hipStreamCreateWithFlags(&ds.stream4, hipStreamNonBlocking));
       }
     }
-    RC_HIP(hipEventCreateWithFlags(&h->ev_inv, hipEventDisableTiming));
   }
+  return 0;
+}
+
+static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
+  const int64_t Np = h->Np;
+  const int M = h->M;
+  RC_HIP(hipSetDevice(h->device));
+  {
+    std::lock_guard<std::mutex> lock(g_streams_mutex);
+    RcDeviceStreams& ds = g_streams[h->device];
+    if (ds.refs == 0) {
+      int rcs = create_streams(h, ds);
+      if (rcs) return rcs;
+    }
+    ++ds.refs;
+    h->streams_acquired = true;
+    h->stream = ds.stream; h->stream2 = ds.stream2; h->stream3 = ds.stream3; h->stream4 = ds.stream4; h->stream5 = ds.stream5;
+    h->stream6 = ds.stream6;
+  }
+  RC_HIP(hipEventCreateWithFlags(&h->ev_inv, hipEventDisableTiming));
   h->launch = h->stream;
   if (const char* e = getenv("RCGP_DIAG")) h->diag_variant = atoi(e);
   if (const char* e = getenv("RCGP_OVERLAP_INVERSE")) h->overlap_ok = (e[0] != '0');
