@@ -108,14 +108,16 @@ static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
     for (int cu = 0; cu < ncu; ++cu)
       if (cu >= reserve) mask[cu / 32] |= (1u << (cu % 32));
+    const char* ov = getenv("RCGP_OVERLAP_INVERSE");
+    const bool want4 = ov && ov[0] != '0';                       // the L^-1 overlap stream only exists when that (rejected) mode is on
     hipError_t me = hipErrorInvalidValue;
     if (reserve > 0 && reserve < ncu) me = hipExtStreamCreateWithCUMask(&ds.stream3, (uint32_t)mask.size(), mask.data());
     if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] %d CUs, reserve %d, CU-mask stream: %s\n", ncu, reserve, hipGetErrorString(me));
     if (me != hipSuccess) {
       (void)hipGetLastError();
       RC_HIP(hipStreamCreateWithFlags(&ds.stream3, hipStreamNonBlocking));
-      RC_HIP(hipStreamCreateWithFlags(&ds.stream4, hipStreamNonBlocking));
-    } else {
+      if (want4) RC_HIP(hipStreamCreateWithFlags(&ds.stream4, hipStreamNonBlocking));
+    } else if (want4) {
       // the overlapped L^-1 kernels run long tiles: confine them to the upper part of the chip so that the panel chain's GEMMs
       // (which want many CUs at once) always find free ones
       int reserve_inv = 128;
@@ -152,7 +154,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   RC_HIP(hipEventCreateWithFlags(&h->ev_inv, hipEventDisableTiming));
   h->launch = h->stream;
   if (const char* e = getenv("RCGP_DIAG")) h->diag_variant = atoi(e);
-  if (const char* e = getenv("RCGP_OVERLAP_INVERSE")) h->overlap_ok = (e[0] != '0');
+  if (const char* e = getenv("RCGP_OVERLAP_INVERSE")) h->overlap_ok = (e[0] != '0') && h->stream4;   // (the device's stream set may predate the knob)
   if (const char* e = getenv("RCGP_LOOKAHEAD")) h->lookahead = (e[0] != '0');     // tuning knob: 0 = strictly sequential potrf
   if (const char* e = getenv("RCGP_FINE")) h->fine_chain = (e[0] != '0');         // 0 = one stream per panel chain (D, T, G in order)
   if (const char* e = getenv("RCGP_EXT")) {
