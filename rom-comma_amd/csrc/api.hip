@@ -7,6 +7,7 @@
 #include <string.h>
 #include <map>
 #include <mutex>
+#include <tuple>
 
 #define RC_API extern "C" __attribute__((visibility("default")))
 #define RC_CHECK_H(h)            \
@@ -24,28 +25,31 @@ RC_API int rcgp_device_count(void) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// One set of streams per device, shared by every handle of the process on that device (reference-counted). Every stream is a
-// hardware queue that the runtime keeps for the life of the process, and the multi-stream Cholesky slows down by a quarter
-// once a few more queues than its own six exist (three handles alive at once: 34 -> 43 ms at C2; DESIGN.md "tried and
-// rejected"). Handles are used one call at a time by their owner, so sharing the streams only orders the work of different
-// handles of one device behind each other. The tuning knobs that shape the streams are read when the set is created.
+// One set of streams per device (and per value of the two knobs that shape them), shared by every handle of the process on that
+// device and kept for the life of the process. Every stream is a hardware queue that the runtime keeps anyway, and the
+// multi-stream Cholesky slows down by a quarter once a few more queues than its own six exist (three handles alive at once: 34 ->
+// 43 ms at C2; DESIGN.md "tried and rejected"). Handles are used one call at a time by their owner, so sharing the streams only
+// orders the work of different handles of one device behind each other. The set is never destroyed: tearing the queues down and
+// building them again for every handle is needless churn in the runtime (and the GPU test suite stalled twice while it did so).
 // ---------------------------------------------------------------------------------------------------------------------
 struct RcDeviceStreams {
   hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr, stream5 = nullptr, stream6 = nullptr;
   int refs = 0;
 };
 static std::mutex g_streams_mutex;
-static std::map<int, RcDeviceStreams> g_streams;
+static std::map<std::tuple<int, int, int>, RcDeviceStreams> g_streams;      // (device, RCGP_RESERVE_CUS, RCGP_RESERVE_CUS_INV)
+
+static std::tuple<int, int, int> streams_key(int device) {
+  int reserve = 24, reserve_inv = 128;
+  if (const char* e = getenv("RCGP_RESERVE_CUS")) reserve = atoi(e);
+  if (const char* e = getenv("RCGP_RESERVE_CUS_INV")) reserve_inv = atoi(e);
+  return std::make_tuple(device, reserve, reserve_inv);
+}
 
 static void release_streams(rcgp_handle_s* h) {
   if (!h->streams_acquired) return;
   std::lock_guard<std::mutex> lock(g_streams_mutex);
-  RcDeviceStreams& ds = g_streams[h->device];
-  if (--ds.refs == 0) {
-    hipStream_t* all[] = {&ds.stream4, &ds.stream6, &ds.stream5, &ds.stream3, &ds.stream2, &ds.stream};
-    for (auto sp : all)
-      if (*sp) { (void)hipStreamDestroy(*sp); *sp = nullptr; }
-  }
+  --g_streams[h->streams_key].refs;                    // bookkeeping only: the set stays
   h->stream = h->stream2 = h->stream3 = h->stream4 = h->stream5 = h->stream6 = nullptr;
   h->streams_acquired = false;
 }
@@ -108,8 +112,7 @@ static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
     for (int cu = 0; cu < ncu; ++cu)
       if (cu >= reserve) mask[cu / 32] |= (1u << (cu % 32));
-    const char* ov = getenv("RCGP_OVERLAP_INVERSE");
-    const bool want4 = ov && ov[0] != '0';                       // the L^-1 overlap stream only exists when that (rejected) mode is on
+    const bool want4 = true;      // (the stream of the rejected L^-1 overlap mode: created with the others, as in every measured build)
     hipError_t me = hipErrorInvalidValue;
     if (reserve > 0 && reserve < ncu) me = hipExtStreamCreateWithCUMask(&ds.stream3, (uint32_t)mask.size(), mask.data());
     if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] %d CUs, reserve %d, CU-mask stream: %s\n", ncu, reserve, hipGetErrorString(me));
@@ -141,10 +144,16 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   RC_HIP(hipSetDevice(h->device));
   {
     std::lock_guard<std::mutex> lock(g_streams_mutex);
-    RcDeviceStreams& ds = g_streams[h->device];
-    if (ds.refs == 0) {
+    h->streams_key = streams_key(h->device);
+    RcDeviceStreams& ds = g_streams[h->streams_key];
+    if (!ds.stream) {
       int rcs = create_streams(h, ds);
-      if (rcs) return rcs;
+      if (rcs) {                                        // leave no half-built set behind
+        hipStream_t* all[] = {&ds.stream4, &ds.stream6, &ds.stream5, &ds.stream3, &ds.stream2, &ds.stream};
+        for (auto sp : all)
+          if (*sp) { (void)hipStreamDestroy(*sp); *sp = nullptr; }
+        return rcs;
+      }
     }
     ++ds.refs;
     h->streams_acquired = true;

@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #define RC_TILE 128            // edge of a workgroup tile and of a diagonal Cholesky block
@@ -31,6 +32,7 @@ struct RcProfEvent { hipEvent_t start, stop; int cls; };
 struct rcgp_handle_s {
   int device = 0;
   bool streams_acquired = false;     // this handle holds a reference on its device's shared stream set (api.hip)
+  std::tuple<int, int, int> streams_key;
   hipStream_t stream = nullptr;      // main stream: every public call is ordered on it
   hipStream_t stream2 = nullptr;     // high-priority side stream: the chain of diagonal kernels (+ k_prep_next) inside rc_potrf
   hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky (CU mask: RCGP_RESERVE_CUS CUs left free)

@@ -77,10 +77,23 @@ __global__ void __launch_bounds__(512, 4) k_gram(double* __restrict__ out, int64
   const double var = FS[bi * L + bj], noise = CROSS ? 0.0 : FS[L * L + bi * L + bj];
   const int64_t ioff = CROSS ? 0 : (int64_t)bi * tb * 128, joff = (int64_t)bj * tb * 128;   // first row / column of the block
   const int t = threadIdx.x;
-  for (int e = t; e < 128 * M; e += 512) {
-    const int rr = e / M, m = e - rr * M;
-    zi[m * ZST + rr] = Zr[((int64_t)ti * 128 + rr) * M + m];
-    zj[m * ZST + rr] = Zc[((int64_t)tj * 128 + rr) * M + m];
+  for (int e0 = t; e0 < 128 * M; e0 += 4 * 512) {    // four loads per panel in flight before the first LDS store (not one round trip each)
+    double vi[4], vj[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + 512 * q;
+      vi[q] = (e < 128 * M) ? Zr[(int64_t)ti * 128 * M + e] : 0.0;
+      vj[q] = (e < 128 * M) ? Zc[(int64_t)tj * 128 * M + e] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + 512 * q;
+      if (e < 128 * M) {
+        const int rr = e / M, m = e - rr * M;
+        zi[m * ZST + rr] = vi[q];
+        zj[m * ZST + rr] = vj[q];
+      }
+    }
   }
   if (t < 128) si[t] = sqr[(int64_t)ti * 128 + t];
   else if (t < 256) sj[t - 128] = sqc[(int64_t)tj * 128 + t - 128];
