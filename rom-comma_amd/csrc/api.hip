@@ -46,6 +46,20 @@ static std::tuple<int, int, int> streams_key(int device) {
   return std::make_tuple(device, reserve, reserve_inv);
 }
 
+// At process exit the sets are destroyed by this handler, registered with the first set: it runs before the HIP runtime (and a
+// profiler's intercept layer) are torn down, which handlers registered at load time outlive -- streams left to the runtime's own
+// teardown crashed rocprofv3 at exit.
+static void destroy_stream_sets() {
+  std::lock_guard<std::mutex> lock(g_streams_mutex);
+  for (auto& kv : g_streams) {
+    RcDeviceStreams& ds = kv.second;
+    if (hipSetDevice(std::get<0>(kv.first)) != hipSuccess) continue;
+    hipStream_t* all[] = {&ds.stream4, &ds.stream6, &ds.stream5, &ds.stream3, &ds.stream2, &ds.stream};
+    for (auto sp : all)
+      if (*sp) { (void)hipStreamDestroy(*sp); *sp = nullptr; }
+  }
+}
+
 static void release_streams(rcgp_handle_s* h) {
   if (!h->streams_acquired) return;
   std::lock_guard<std::mutex> lock(g_streams_mutex);
@@ -147,6 +161,8 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     h->streams_key = streams_key(h->device);
     RcDeviceStreams& ds = g_streams[h->streams_key];
     if (!ds.stream) {
+      static bool registered = false;
+      if (!registered) { atexit(destroy_stream_sets); registered = true; }
       int rcs = create_streams(h, ds);
       if (rcs) {                                        // leave no half-built set behind
         hipStream_t* all[] = {&ds.stream4, &ds.stream6, &ds.stream5, &ds.stream3, &ds.stream2, &ds.stream};
