@@ -40,7 +40,7 @@ static std::mutex g_streams_mutex;
 static std::map<std::tuple<int, int, int>, RcDeviceStreams> g_streams;      // (device, RCGP_RESERVE_CUS, RCGP_RESERVE_CUS_INV)
 
 static std::tuple<int, int, int> streams_key(int device) {
-  int reserve = 24, reserve_inv = 128;
+  int reserve = RC_RESERVE_CUS_DEFAULT, reserve_inv = 128;
   if (const char* e = getenv("RCGP_RESERVE_CUS")) reserve = atoi(e);
   if (const char* e = getenv("RCGP_RESERVE_CUS_INV")) reserve_inv = atoi(e);
   return std::make_tuple(device, reserve, reserve_inv);
@@ -117,8 +117,11 @@ static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
     RC_HIP(hipStreamCreateWithPriority(&ds.stream6, hipStreamNonBlocking, hi));
   }
   {
-    // The bulk-update stream may use every CU except the first RCGP_RESERVE_CUS, which stay free for the panel chain.
-    int reserve = 24;
+    // The bulk-update stream may be confined to every CU except the first RCGP_RESERVE_CUS, which then stay free for the panel chain.
+    // Default 0 = no mask: with the chain kernels of this build a reserve no longer pays at C2 (33.5 vs 33.4 ms with 24 CUs held back)
+    // and costs 2.4 % at N = 28672 (142.3 vs 138.9 ms), and a process without CU-masked queues cannot run into the slow regime that
+    // two active ones cause.
+    int reserve = RC_RESERVE_CUS_DEFAULT;
     if (const char* e = getenv("RCGP_RESERVE_CUS")) reserve = atoi(e);
     hipDeviceProp_t prop;
     RC_HIP(hipGetDeviceProperties(&prop, h->device));

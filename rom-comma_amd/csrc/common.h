@@ -12,6 +12,7 @@
 #define RC_BK 16               // k-depth of one LDS stage of the MFMA GEMM
 #define RC_MAX_M 64            // largest input dimensionality supported by the fused kernels
 #define RC_MAX_L 16            // most outputs of one covariant GP
+#define RC_RESERVE_CUS_DEFAULT 0   // CUs the bulk-update stream leaves to the panel chain (RCGP_RESERVE_CUS); 0 = no CU mask
 #define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -35,8 +36,8 @@ struct rcgp_handle_s {
   std::tuple<int, int, int> streams_key;
   hipStream_t stream = nullptr;      // main stream: every public call is ordered on it
   hipStream_t stream2 = nullptr;     // high-priority side stream: the chain of diagonal kernels (+ k_prep_next) inside rc_potrf
-  hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky (CU mask: RCGP_RESERVE_CUS CUs left free)
-  hipStream_t stream4 = nullptr;     // L^-1 kernels overlapped with the chain-bound tail of the Cholesky (same CU mask as stream3)
+  hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky (with RCGP_RESERVE_CUS = n > 0: CU mask, n CUs left free)
+  hipStream_t stream4 = nullptr;     // L^-1 kernels overlapped with the chain-bound tail of the Cholesky (rejected mode; masked like stream3 when that is)
   hipStream_t stream5 = nullptr;     // column work of the fine-grained panel chain (T2/G kernels, potrf.hip)
   hipStream_t stream6 = nullptr;     // the far part of that column work (block columns the next chain step does not read)
   int prep_split = 2;                // the chain's critical step as k_prep1 + k_prep2 on several CUs (2: k_prep1 with 8 waves, 1: 4 waves) instead of k_prep_next on one (0) (RCGP_PSPLIT)

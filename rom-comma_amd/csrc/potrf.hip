@@ -586,7 +586,7 @@ static int next_event(rcgp_handle_s* h, hipEvent_t* out) {
 //                                   behind the earlier far parts; it is the far part that waits for the window piece below).
 //   U1 (h->stream, main)          : when panel p = [pend-NB, pend) is complete, its K=NB update of the next `depth` column panels
 //                                   from u0 on, one kernel each, nearest first (window pieces);
-//   U2 (h->stream3, CU-masked)    : ... and of everything beyond them (the bulk of the flops), concurrently with the next chain.
+//   U2 (h->stream3)               : ... and of everything beyond them (the bulk of the flops), concurrently with the next chain.
 // cend = pend + EXT: the G updates reach EXT columns past their own panel, so the first blocks of the NEXT panel are already
 // up to date when the chain arrives there (u0 = pend + EXT): the chain itself never waits for a window piece, only the far part
 // (and the near part once it reaches column u0) does. Events ride on the dispatches (RC_LAUNCH, h->launch_stop).
@@ -688,7 +688,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
       u0_prev = pend + EXT;
       // Outer (K = NB) updates with the finished panel, by target column panel: the next `depth` (shifted) panels one kernel
       // each, in column order on the main stream -- the first one is what the chain is waiting for -- and everything beyond
-      // them in one bulk kernel on the CU-masked stream. A column panel leaves the bulk kernel's domain one panel before the
+      // them in one bulk kernel on the bulk stream. A column panel leaves the bulk kernel's domain one panel before the
       // chain reaches it with depth 1, `depth` panels before with a deeper window: the chain may run that far ahead of the bulk.
       eU1_prev = nullptr;
       const int depth = h->chain_depth;
