@@ -103,7 +103,25 @@ __global__ void __launch_bounds__(256) k_gemvT_partial(const double* __restrict_
   if (j < Np) {
     int64_t k0 = (j >> 7) << 7;
     if (k0 < k0c) k0 = k0c;
-    for (int64_t k = k0; k < k1; ++k) s = fma(Linv[k * ld + j], w[k], s);
+    // eight loads in flight per lane and four independent accumulators (fixed order: bit-reproducible); one dependent fma per load
+    // left the kernel at 2.9 TB/s
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = Linv[(k + q) * ld + j];
+      s0 = fma(v[0], w[k], s0);
+      s1 = fma(v[1], w[k + 1], s1);
+      s2 = fma(v[2], w[k + 2], s2);
+      s3 = fma(v[3], w[k + 3], s3);
+      s0 = fma(v[4], w[k + 4], s0);
+      s1 = fma(v[5], w[k + 5], s1);
+      s2 = fma(v[6], w[k + 6], s2);
+      s3 = fma(v[7], w[k + 7], s3);
+    }
+    for (; k < k1; ++k) s0 = fma(Linv[k * ld + j], w[k], s0);
+    s = (s0 + s1) + (s2 + s3);
     partial[(int64_t)blockIdx.y * Np + j] = s;
   }
 }
