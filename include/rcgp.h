@@ -18,8 +18,10 @@
  *   rcgp_sobol_error_terms        ClosedSobolWithError: mu_phi_mu, psi_factor, mu_psi_mu          gsa/calibrators.py:259-322
  *
  * Conventions: all matrices row-major float64; the caller owns every host buffer; the library owns device memory inside
- * the opaque handle until rcgp_destroy. A handle is bound to one device and one HIP stream; it is not thread-safe;
- * distinct handles are independent. Return value: 0 = ok; k > 0 = LAPACK-style "leading minor k is not positive
+ * the opaque handle until rcgp_destroy. A handle is bound to one device; it is not thread-safe. Distinct handles are
+ * independent in what they compute, but all handles of a process on one device share one set of HIP streams (created with
+ * the first handle, kept for the life of the process): their work is ordered behind each other on the device, so using two of
+ * them from two threads gains nothing over using them in turn. Return value: 0 = ok; k > 0 = LAPACK-style "leading minor k is not positive
  * definite" (TensorFlow raises InvalidArgumentError there); < 0 = bad argument (-1..-9) or HIP error (-100 - hipError_t).
  * rcgp_last_error gives the message. One process per GPU for multi-GPU runs.
  */
