@@ -41,6 +41,13 @@ def sobol_indices(V, M):
     return np.concatenate([V[:M] / full, V[M:2 * M] / full, 1.0 - V[2 * M:3 * M] / full])
 
 
+def fold_schedule(rank, warmup, steps, n_folds):
+    """The fold every step of one rank fits, warm-up steps first: timed step s takes fold (rank + s) mod n_folds, the warm-up steps
+    the folds before `rank`. A K-fold cross-validation handed round the GPUs: one fold per GPU and step, and over the steps every
+    rank meets the cheap and the expensive folds alike."""
+    return [(rank - warmup + s) % n_folds for s in range(warmup + steps)]
+
+
 def pmc_traffic(N, M, kernel='k_grad'):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_c2.json, produced by
     tools/pmc_summary.py with the gfx950 FETCH_SIZE correction). Counters cannot be read inside this process, so the number
@@ -123,7 +130,7 @@ def main():
         # rank meets the cheap and the expensive folds alike (the folds' fits take 71-86 L-BFGS-B evaluations at C2) and one step
         # still is one fold per GPU. Every fold this rank will meet is resident in HBM before the timed region starts.
         # (Warm-up steps take the folds before r, so that timed step s is fold r + s.)
-        units = [(rank - args.warmup + s) % K_folds for s in range(n_steps_total)]
+        units = fold_schedule(rank, args.warmup, args.steps, K_folds)
         handles = {}
         for k in dict.fromkeys(units):
             Xk, yk = synthetic_cv_fold(N, M, k=k, K=K_folds)

@@ -186,3 +186,17 @@ def test_hipgp_stores_and_missing_gpu(tmp_path):
     if _lib.device_count() <= 0:
         with pytest.raises(_lib.RcgpError):                            # compute fails loudly without a device
             gp.predict(np.zeros((2, 3)))
+
+
+def test_bench_fold_schedule():
+    """bench.py hands the folds of the 8-fold split round the ranks: one fold per rank and step, timed step s of rank r = fold r + s."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench', str(Path(__file__).resolve().parent.parent / 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.fold_schedule(0, 1, 2, 8) == [7, 0, 1]
+    assert bench.fold_schedule(5, 1, 3, 8) == [4, 5, 6, 7]
+    for s in range(3):                                                   # every step: the 8 ranks hold 8 different folds
+        assert sorted(bench.fold_schedule(r, 1, 3, 8)[1 + s] for r in range(8)) == list(range(8))
+    totals = {tuple(sorted(bench.fold_schedule(r, 0, 8, 8))) for r in range(8)}
+    assert totals == {tuple(range(8))}                                   # over 8 steps every rank has fitted every fold once
