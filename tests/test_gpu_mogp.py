@@ -269,3 +269,27 @@ def test_full_size_properties():
     assert np.allclose(gell_b, gell_a[P], rtol=1e-6, atol=1e-7 * np.abs(gell_a).max())
     assert np.allclose(gF_b, gF_a[np.ix_(P, P)], rtol=1e-6, atol=1e-7 * np.abs(gF_a).max())
     assert np.allclose(gS_b, gS_a[np.ix_(P, P)], rtol=1e-6, atol=1e-7 * np.abs(gS_a).max())
+
+
+def test_random_shapes_against_oracle():
+    """A spread of sizes around the tile and panel boundaries (N just below / at / above multiples of 128, L N crossing 512 where
+    the multi-stream factorisation starts, M from 1 to 12), each checked against the oracle: LML, all three gradients, predict."""
+    from oracle import mogp_oracle as mo
+    from romcomma_amd import _lib
+    rng = np.random.default_rng(2024)
+    cases = [(127, 1, 2), (128, 2, 2), (129, 3, 2), (255, 5, 2), (256, 2, 3), (257, 7, 2), (171, 12, 3), (383, 4, 4), (512, 3, 2),
+             (640, 6, 2), (90, 2, 5), (333, 1, 3)]
+    for i, (N, M, L) in enumerate(cases):
+        X, Y, ell, F, S = _case(N, M, L, seed=100 + i)
+        ell = ell * (1.0 + 0.5 * rng.random())
+        Xs = rng.standard_normal((37, M))
+        v, dF, dell, dS = mo.lml_and_grad(X, Y, ell, F, S)
+        mean, sd = mo.predict(X, Y, ell, F, S, Xs)
+        with _lib.RcMOGP(X, Y) as gp:
+            gp.set_hyper(ell, F, S)
+            lml, gF, gell, gS = gp.lml_grad()
+            m, s = gp.predict(Xs)
+        assert lml == pytest.approx(v, rel=1e-10), (N, M, L)
+        for got, ref in ((gF, dF), (gell, dell), (gS, dS)):
+            assert np.abs(got - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max()), (N, M, L)
+        assert np.allclose(m, mean, rtol=1e-8, atol=1e-9) and np.allclose(s, sd, rtol=1e-7, atol=1e-9), (N, M, L)

@@ -446,3 +446,33 @@ def test_full_size_evaluation_is_bitwise_reproducible(gpu):
                 ref = (lml, grad, alpha)
             else:
                 assert lml == ref[0] and np.array_equal(grad, ref[1]) and np.array_equal(alpha, ref[2])
+
+
+def test_random_shapes_against_oracle(gpu):
+    """Independent GP over a spread of sizes around the tile (128), fine-chain (512) and outer-panel (1024) boundaries and M from 1
+    to 33 (both LDS layouts of the gradient kernel): LML, gradient, K_inv_Y, predict and all Sobol slices against the oracle."""
+    rng = np.random.default_rng(7)
+    cases = [(127, 1), (128, 2), (129, 3), (255, 9), (511, 4), (512, 5), (513, 2), (1023, 3), (1024, 6), (1025, 33), (1151, 8),
+             (1400, 12), (2049, 5)]
+    for i, (N, M) in enumerate(cases):
+        X, y = o.synthetic_fold(N, M, k=20 + i)
+        ell = 0.6 + 2.5 * rng.random(M)
+        var, noise = 0.5 + rng.random(), 0.005 + 0.03 * rng.random()
+        Xs = o.synthetic_fold(41, M, k=70 + i)[0]
+        v, g = o.lml_and_grad(X, y, ell, var, noise)
+        mean, sd = o.predict(X, y, ell, var, noise, Xs)
+        alpha = o.k_inv_y(X, y, ell, var, noise)
+        slices = o.all_slices(M)[:12] + [(0, M)]
+        with gpu.RcGP(X, y) as gp:
+            gp.set_hyper(ell, var, noise)
+            lml, grad = gp.lml_grad()
+            a = gp.k_inv_y()
+            m, s = gp.predict(Xs)
+            V = gp.sobol_closed(slices)
+        ref = o.ClosedSobolOracle(X, alpha[None, None, :], np.array([[var]]), ell[None, :])
+        Vref = np.array([ref.marginalize(sl)['V'][0, 0] for sl in slices])
+        assert lml == pytest.approx(v, rel=1e-10), (N, M)
+        assert np.abs(grad - g).max() <= 1e-7 * max(1.0, np.abs(g).max()), (N, M)
+        assert np.allclose(a, alpha, rtol=1e-6, atol=1e-8 * np.abs(alpha).max()), (N, M)
+        assert np.allclose(m, mean, rtol=1e-8, atol=1e-9) and np.allclose(s, sd, rtol=1e-7, atol=1e-9), (N, M)
+        assert np.allclose(V, Vref, rtol=1e-8, atol=1e-10 * np.abs(Vref).max()), (N, M)      # (the empty slice is 0 up to rounding)
