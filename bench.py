@@ -49,44 +49,78 @@ def fold_schedule(rank, warmup, steps, n_folds):
 
 
 def pmc_traffic(N, M, kernel='k_grad'):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_c2.json, produced by
-    tools/pmc_summary.py with the gfx950 FETCH_SIZE correction). Counters cannot be read inside this process, so the number
-    is the profiled one for the same workload; None for any other size."""
-    path = ROOT / 'profiles' / 'r01_pmc_c2.json'
-    if (N, M) != (16384, 10) or not path.exists():
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_c2.json, falling back to the
+    round-1 file; produced by tools/pmc_summary.py with the gfx950 FETCH_SIZE correction). Counters cannot be read inside this
+    process, so the number is the profiled one for the same workload and build; None for any other size."""
+    if (N, M) != (16384, 10):
         return None
-    try:
-        return float(json.load(open(path))[kernel]['hbm_bytes_per_launch'])
-    except Exception:
-        return None
+    for name in ('r02_pmc_c2.json', 'r01_pmc_c2.json'):
+        path = ROOT / 'profiles' / name
+        if path.exists():
+            try:
+                return float(json.load(open(path))[kernel]['hbm_bytes_per_launch'])
+            except Exception:
+                continue
+    return None
 
 
-def cpu_baseline(N, M, nfev):
-    """The oracle timed on this box's host cores on a bounded sample, scaled to the workload (N^3 for an LML+gradient
-    evaluation, N^2 for the Sobol quadratic forms)."""
-    from oracle import gp_oracle as o
+def _blas_info():
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+        pools = [p for p in threadpool_info() if p.get('user_api') == 'blas'] or threadpool_info()
+        cores = max([p.get('num_threads', 1) for p in pools] or [1])
+        vendor = ', '.join(sorted({f"{p.get('internal_api', '?')} {p.get('version', '')}".strip() for p in pools})) or 'unknown'
+        return int(cores), vendor
     except Exception:
-        cores = os.cpu_count() or 1
-    ne, ns = min(N, 4096), min(N, 2048)
-    X, y = o.synthetic_fold(ne, M)
-    ell, var, noise = o.bench_hyper(M)
+        return int(os.cpu_count() or 1), 'unknown'
+
+
+def _cpu_times(o, N, M, sobol_rows, fit=False):
+    """Wall times of the oracle on this host at one configuration: one LML+gradient evaluation fully timed at (N, M); the 3M+1 Sobol
+    quadratic forms on a stripe of `sobol_rows` rows against all N columns, scaled by N / sobol_rows (the work per row is uniform);
+    with `fit`, a whole L-BFGS-B fit as well (small sizes only)."""
+    X, y = o.synthetic_fold(N, M)
+    ell, var, _ = o.bench_hyper(M)
+    noise = 1e-2
     t0 = time.perf_counter()
-    o.lml_and_grad(X, y, ell, var, 1e-2)
-    te = time.perf_counter() - t0
-    Xs, ys = o.synthetic_fold(ns, M)
-    alpha = o.k_inv_y(Xs, ys, ell, var, 1e-2)
-    g, phi = o.sobol_prepare(Xs, alpha[None, :], np.array([var]), ell[None, :])
+    o.lml_and_grad_blas(X, y, ell, var, noise)
+    t_eval = time.perf_counter() - t0
+    out = {'N': N, 'M': M, 'evaluation_s': t_eval}
+    if fit:
+        t0 = time.perf_counter()
+        res = o.fit(X, y, 5.0 * np.ones(M))
+        out['fit_s'] = time.perf_counter() - t0
+        out['fit_evaluations'] = int(res['nfev'])
+    alpha = o.k_inv_y(X, y, ell, var, noise)
+    g, phi = o.sobol_prepare(X, alpha[None, :], np.array([var]), ell[None, :])
+    rows = min(N, sobol_rows)
     t0 = time.perf_counter()
-    o.sobol_V_pair(Xs, g[0], g[0], phi[0], phi[0], o.all_slices(M))
-    ts = time.perf_counter() - t0
-    t_full = nfev * te * (N / ne) ** 3 + ts * (N / ns) ** 2
-    return {'value': N / t_full, 'unit': 'train-points/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'oracle (NumPy/SciPy fp64): 1 LML+gradient evaluation at N={ne} ({te:.2f} s) scaled by (N/{ne})^3 x {nfev} '
-                      f'evaluations + {3 * M + 1} Sobol quadratic forms at N={ns} ({ts:.2f} s) scaled by (N/{ns})^2; '
-                      f'estimated fit+Sobol wall time {t_full:.1f} s'}
+    o.sobol_V_pair(X, g[0], g[0], phi[0], phi[0], o.all_slices(M), rows=(0, rows))
+    out['sobol_s'] = (time.perf_counter() - t0) * N / rows
+    out['sobol_sample_rows'] = rows
+    return out
+
+
+def cpu_baseline(N, M, nfev_per_step):
+    """The oracle (NumPy/SciPy fp64, `oracle/gp_oracle.py`: LAPACK potrf + potri, BLAS-3 gradient sums) timed on this box's host
+    cores AT the benchmark's configuration: one real LML+gradient evaluation at (N, M), times the evaluation count the GPU fit
+    needed (the same SciPy driver would take the same path), plus the Sobol forms from a row stripe. SURVEY.md 8d's C0 and C1
+    are timed beside it. A reported baseline, not the target; conservative: GPflow autodiff does more work per evaluation."""
+    from oracle import gp_oracle as o
+    cores, vendor = _blas_info()
+    o.lml_and_grad_blas(*o.synthetic_fold(512, M), *o.bench_hyper(M)[:2], 1e-2)      # BLAS threads up, pages touched: not timed
+    configs = {}
+    if (N, M) == (16384, 10):
+        configs['C0'] = _cpu_times(o, 256, 3, 256, fit=True)
+        configs['C1'] = _cpu_times(o, 8192, 5, 256)
+    main = _cpu_times(o, N, M, 256 if N > 4096 else N)
+    configs['C2' if (N, M) == (16384, 10) else 'bench'] = main
+    t_full = nfev_per_step * main['evaluation_s'] + main['sobol_s']
+    return {'value': N / t_full, 'unit': 'train-points/s', 'cores': cores, 'kind': 'port', 'blas': vendor,
+            'sample': f'oracle.lml_and_grad_blas timed once at the full N={N}, M={M} ({main["evaluation_s"]:.2f} s) x {nfev_per_step:.1f} evaluations per '
+                      f'fit (the GPU fit\'s count) + {3 * M + 1} Sobol quadratic forms timed on a {main["sobol_sample_rows"]}-row stripe x N/{main["sobol_sample_rows"]} '
+                      f'({main["sobol_s"]:.1f} s); fit+Sobol wall time {t_full:.1f} s on {cores} threads ({vendor})',
+            'configs': configs}
 
 
 def main():
@@ -140,13 +174,14 @@ def main():
                                                                         # factor): its work buffers (L^-1, scratch) exist before the timed region
     slices = all_slices(M)
     last = {}
-    counter = {'s': 0}
+    counter = {'s': 0, 'nfev': 0}
     gp = handles[units[-1]]                          # the handle of the last timed step: profiled launches, stand-alone stages
 
     def step(profiled=False):
         gp = handles[units[counter['s']]]
         counter['s'] += 1
         fit = fit_lbfgsb(gp, 5.0 * np.ones(M), 2.0, 0.02)
+        counter['nfev'] += int(fit['nfev'])
         if profiled:
             gp.set_profiling(True)
         V = gp.sobol_closed(slices)
@@ -160,6 +195,7 @@ def main():
         h.profile_reset()
         h.sync()
     dist.barrier()
+    counter['nfev'] = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         # Per-launch HIP events cost ~5 % (profiled dispatches, marker packets on the panel chain, harvesting), so by default
@@ -204,6 +240,7 @@ def main():
         achieved = grad_flops / (ms_grad * 1e-3) / 1e12 if ms_grad > 0 else 0.0
         family = (flops + grad_flops) / ((ms_gemm + ms_grad) * 1e-3) / 1e12 if ms_gemm + ms_grad > 0 else 0.0
         nfev = int(last['fit']['nfev'])
+        nfev_total = int(counter['nfev'])                    # rank 0's L-BFGS-B evaluations over the timed steps
         out = {
             'metric': 'GP-fit+Sobol train-points/s (wall-time per fit+Sobol in ms_per_step), fp64',
             'value': world * N * args.steps / elapsed,
@@ -214,7 +251,8 @@ def main():
             'config': {'workload': f'{"C2" if (N, M) == (16384, 10) else "custom"}: ARD-RBF GP fit (L-BFGS-B to convergence, reference defaults) + closed-form Sobol first/closed/'
                                    f'total indices, N={N}, M={M}, ' + (f'L=1, fold (r + step) mod {K_folds} of an {K_folds}-fold split on GPU r' if args.shard == 'folds' else
                                                           f'output r of {max(8, world)} independent outputs on one design per GPU'),
-                       'N': N, 'M': M, 'lbfgs_evaluations_last_step': nfev, 'parallelism': f'{args.shard[:-1]}-per-gpu x{world}',
+                       'N': N, 'M': M, 'lbfgs_evaluations_last_step': nfev, 'lbfgs_evaluations_timed_steps': nfev_total,
+                       'ms_per_evaluation_incl_host': 1e3 * elapsed / max(nfev_total, 1), 'parallelism': f'{args.shard[:-1]}-per-gpu x{world}',
                        'log_marginal': last['fit']['log_marginal']},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic(N, M),
@@ -236,8 +274,10 @@ def main():
                 'timed_region_ms': 1e3 * elapsed, 'steps_with_hip_events': args.profile_steps,
                        'evaluations_with_hip_events': f'every {args.profile_every}-th of a profiled step'},
         }
+        out['roofline']['stages'] = {k: {kk: vv for kk, vv in out['stages'][k].items() if kk in ('bound', 'frac', 'achieved_GBs', 'achieved_TFLOPs', 'ms', 'avg_launch_ms')}
+                                     for k in ('gram', 'cholesky')}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(N, M, nfev)
+            out['cpu_baseline'] = cpu_baseline(N, M, nfev_total / max(args.steps, 1))
         print(json.dumps(out), flush=True)
     for h in handles.values():
         h.close()

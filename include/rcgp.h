@@ -69,7 +69,8 @@ int rcgp_predict(rcgp_handle h, int64_t n, const double* Xnew, int include_noise
 
 /* Gradient GP at n points (gpr/models.py:386-415): mean[(o*M + m)] = sum_N d k(X_N, x_o)/d x_om * alpha_N and
  * cov[(O*M + P) * (n*M) + (o*M + p)] = sum_N V[N][O,P] V[N][o,p] with V = L^-1 d k(X, x)/dx. The caller forms the reference's
- * var = -cov + diag term. n * M <= 4096. */
+ * var = -cov + diag term. Any n: the n * M derivative rows are processed 4096 at a time (memory for Np * n*M + (n*M)^2 doubles is the
+ * only bound). */
 int rcgp_predict_gradient(rcgp_handle h, int64_t n, const double* Xnew, double* mean, double* cov);
 
 /* Closed-form Sobol conditional variances for this handle's output: V[s] for each slice [slices[2s], slices[2s+1]) of
@@ -83,11 +84,13 @@ int rcgp_sobol_cross(rcgp_handle h, const double* ell_j, double var_j, const dou
 /* Ingredients of the standard errors T, W of the Sobol indices (ClosedSobolWithError, gsa/calibrators.py:146-402) for the
  * output pair (a, b): b = this handle's output (its Cholesky factor enters through psi_factor, :290-309); a = the same output
  * when ell_a == alpha_a == NULL, else the output with lengthscales ell_a[M], kernel variance var_a and alpha_a[N] = K_a^-1 y_a.
- * For every slice s (first-order [m,m+1), closed [0,m) or total-complement [m,M) only) four numbers, WITHOUT the doubling of
+ * For every slice s -- ANY [m0, m1) as in ClosedSobolWithError.marginalize (:348-373); the first-order [m,m+1), closed [0,m) and
+ * total-complement [m,M) slices that GSA asks for all come from one pass -- four numbers, WITHOUT the doubling of
  * a == b entries the reference applies (:281, :284, :322):
  *   phi_d = mu_phi_mu term of the DIAGONAL rank equations (:259-288), psi_d = |psi_factor_ab|^2 (:311-322),
  *   phi_m, psi_m = the same under the MIXED rank equation (used when is_T_partial is false).
- * The caller assembles W = (phi - psi) + transpose and T (:324-346). Requires rcgp_factor; M <= 29. */
+ * The caller assembles W = (phi - psi) + transpose and T (:324-346). Requires rcgp_factor. Any M <= 64 (beyond M = 29 the canonical
+ * slices take several passes: their column accumulators no longer fit in LDS together). */
 int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var_a, const double* alpha_a, int n_slices, const int32_t* slices,
                            double* phi_d, double* psi_d, double* phi_m, double* psi_m);
 
@@ -110,7 +113,7 @@ int rcgp_predict_mo(rcgp_handle h, int64_t n, const double* Xnew, int include_no
  * at point o. mean[r] = sum_{(Lb,N)} dK[(Lb,N)][r] alpha[(Lb,N)]; cov[Lb][r][r'] = sum_N V[(Lb,N)][r] V[(Lb,N)][r'] with
  * V = L^-1 dK, ONE product per training output block Lb -- the reference's einsum 'LNlOM, LNlom -> OLolMm' (:398) keeps that index.
  * cov holds L * (L n M)^2 doubles; the caller applies the sign, picks l = l' and adds the diagonal term (:399-400, :406).
- * L * n * M <= 4096. */
+ * Any n (rows processed 4096 at a time). */
 int rcgp_predict_gradient_mo(rcgp_handle h, int64_t n, const double* Xnew, double* mean, double* cov);
 /* Closed-form Sobol with a non-diagonal F (gsa/calibrators.py:60-97 with is_F_diagonal false) works on "virtual outputs"
  * p = (l, J): phi_p = 1/(ell_l ell_J + 1), pre_p = F[l][J] sqrt(prod_m ell_lm ell_Jm phi_pm), alpha_p = K_inv_Y[J]. Weight vector

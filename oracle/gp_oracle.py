@@ -160,6 +160,48 @@ def lml_and_grad(X, y, ell, var, noise) -> Tuple[float, np.ndarray]:
     return value, np.concatenate([g_ell, [g_var, g_noise]])
 
 
+def lml_and_grad_blas(X, y, ell, var, noise) -> Tuple[float, np.ndarray]:
+    """The same LML and gradient as ``lml_and_grad`` (same formulas) arranged for a many-core host: LAPACK
+    potrf + potri for K_n^-1 (N^3 flops in all, multi-threaded) and BLAS-3 products for the gradient sums instead of M
+    Python-level passes over N x N temporaries. This is what ``bench.py``'s ``cpu_baseline`` times -- the reference's own CPU
+    path (GPflow on TensorFlow: Cholesky + reverse-mode autodiff through it) does strictly more arithmetic, so the baseline is
+    conservative. With r = (W o K) 1 and W = alpha alpha^T - K_n^-1:
+        sum_ij W_ij K_ij (x_im - x_jm)^2 = 2 sum_i x_im^2 r_i - 2 x_m^T (W o K) x_m ,
+        (W o K) V = alpha o (K (alpha o V)) - (K_n^-1 o K) V        for any N x c matrix V (here V = [X, 1]).
+    Only the lower triangle of K_n^-1 is formed (dpotri) and used (dsymm)."""
+    from scipy.linalg import blas, lapack
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    N, M = X.shape
+    ell = np.atleast_1d(np.asarray(ell, dtype=np.float64))
+    isotropic = ell.shape[0] == 1 and M > 1
+    ell_full = np.broadcast_to(ell, (M,)) if isotropic else ell
+    K = gram(X, ell_full, var)
+    A = np.array(K, order='F')
+    A[np.diag_indices(N)] += noise
+    c, info = lapack.dpotrf(A, lower=1, overwrite_a=1)
+    if info != 0:
+        raise np.linalg.LinAlgError(f'leading minor {info} is not positive definite')
+    w = scipy.linalg.solve_triangular(c, y, lower=True, check_finite=False)
+    value = float(-0.5 * w @ w - 0.5 * N * LOG_2PI - np.sum(np.log(np.diag(c))))
+    alpha = scipy.linalg.solve_triangular(c, w, lower=True, trans='T', check_finite=False)
+    Kinv, info = lapack.dpotri(c, lower=1, overwrite_c=1)               # lower triangle of K_n^-1
+    trace_Kinv = float(np.trace(Kinv))
+    np.multiply(Kinv, K, out=Kinv)                                      # K_n^-1 o K (lower triangle meaningful)
+    V = np.concatenate([X, np.ones((N, 1))], axis=1)
+    P = K @ (alpha[:, None] * V)                                        # K (alpha o V)
+    Q = blas.dsymm(1.0, Kinv, np.asfortranarray(V), side=0, lower=1)    # (K_n^-1 o K) V from the lower triangle
+    WKV = alpha[:, None] * P - Q                                        # (W o K) [X, 1]
+    r = WKV[:, M]
+    quad = np.einsum('im,im->m', X, WKV[:, :M])                         # x_m^T (W o K) x_m
+    g_ell = 0.5 * (2.0 * (X * X).T @ r - 2.0 * quad) / ell_full ** 3
+    if isotropic:
+        g_ell = np.array([g_ell.sum()])
+    g_var = 0.5 * np.sum(r) / var
+    g_noise = 0.5 * (alpha @ alpha - trace_Kinv)
+    return value, np.concatenate([g_ell, [g_var, g_noise]])
+
+
 def pack_unconstrained(ell, var, noise) -> np.ndarray:
     """theta -> u, GPflow parametrisation: ell, var = softplus(u); noise = 1e-6 + softplus(u)."""
     ell = np.atleast_1d(np.asarray(ell, dtype=np.float64))
@@ -331,20 +373,22 @@ def sobol_prepare(X: np.ndarray, alpha: np.ndarray, F: np.ndarray, lengthscales:
     return g, phi
 
 
-def sobol_V_pair(X, g_l, g_j, phi_l, phi_j, slices: Iterable[Sequence[int]], block: int = 1024) -> np.ndarray:
+def sobol_V_pair(X, g_l, g_j, phi_l, phi_j, slices: Iterable[Sequence[int]], block: int = 1024, rows: Tuple[int, int] | None = None) -> np.ndarray:
     """V_lj for each dim-slice [a,b):  sum_{n,n'} g_l[n] g_j[n'] prod_{m in slice} h_m(n,n') with
     log h_m = -1/2 log(1-a_m) - 1/2 a_m [phi_l x_n^2 + phi_j x_n'^2 - 2 x_n x_n'] / (1-a_m),  a_m = phi_l,m phi_j,m
-    (algebraic reduction of gsa/calibrators.py:69-79; for l=j this is SURVEY.md Appendix A)."""
+    (algebraic reduction of gsa/calibrators.py:69-79; for l=j this is SURVEY.md Appendix A).
+    ``rows = (r0, r1)`` restricts the n-sum to that stripe (the timing sample of bench.py: the work per row is uniform)."""
     slices = [tuple(int(v) for v in s) for s in slices]
     N, M = X.shape
+    r_lo, r_hi = (0, N) if rows is None else rows
     a = phi_l * phi_j
     c0 = -0.5 * np.log1p(-a)
     c2 = a / (1.0 - a)
     rl = -0.5 * c2 * phi_l * X * X            # (N,M) depends on row index n
     rj = -0.5 * c2 * phi_j * X * X            # (N,M) depends on column index n'
     out = np.zeros(len(slices))
-    for i0 in range(0, N, block):
-        i1 = min(N, i0 + block)
+    for i0 in range(r_lo, r_hi, block):
+        i1 = min(r_hi, i0 + block)
         for j0 in range(0, N, block):
             j1 = min(N, j0 + block)
             t = (c0[None, None, :] + rl[i0:i1, None, :] + rj[None, j0:j1, :]

@@ -29,8 +29,11 @@ RC_API int rcgp_device_count(void) {
 // device and kept for the life of the process. Every stream is a hardware queue that the runtime keeps anyway, and the
 // multi-stream Cholesky slows down by a quarter once a few more queues than its own six exist (three handles alive at once: 34 ->
 // 43 ms at C2; DESIGN.md "tried and rejected"). Handles are used one call at a time by their owner, so sharing the streams only
-// orders the work of different handles of one device behind each other. The set is never destroyed: tearing the queues down and
-// building them again for every handle is needless churn in the runtime (and the GPU test suite stalled twice while it did so).
+// orders the work of different handles of one device behind each other. The set is kept until process exit: tearing six hardware
+// queues down and building them again for every handle is needless churn in the runtime. (Round 1 did that, in an order the HIP
+// contract does not cover -- only the main stream joined, events destroyed ahead of the streams that carried them, queues
+// destroyed while their last marker packets could still be outstanding -- and the GPU test suite stalled twice; DESIGN.md section 6
+// lists what was wrong. Every teardown below now joins ALL streams of the set first.)
 // ---------------------------------------------------------------------------------------------------------------------
 struct RcDeviceStreams {
   hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr, stream5 = nullptr, stream6 = nullptr;
@@ -55,9 +58,20 @@ static void destroy_stream_sets() {
     RcDeviceStreams& ds = kv.second;
     if (hipSetDevice(std::get<0>(kv.first)) != hipSuccess) continue;
     hipStream_t* all[] = {&ds.stream4, &ds.stream6, &ds.stream5, &ds.stream3, &ds.stream2, &ds.stream};
+    for (auto sp : all)                                   // every queue idle before the first one goes
+      if (*sp) (void)hipStreamSynchronize(*sp);
     for (auto sp : all)
       if (*sp) { (void)hipStreamDestroy(*sp); *sp = nullptr; }
   }
+}
+
+// Join every stream a handle can have work on. The multi-stream Cholesky ends with the main stream waiting for its side streams,
+// so after a call that returned normally the main stream alone would do; a call that failed half-way (a HIP error between two
+// launches) leaves the side streams running on their own, and the handle's buffers and events must outlive that work.
+static void join_streams(rcgp_handle_s* h) {
+  hipStream_t all[] = {h->stream2, h->stream5, h->stream6, h->stream3, h->stream4, h->stream};
+  for (auto s : all)
+    if (s) (void)hipStreamSynchronize(s);
 }
 
 static void release_streams(rcgp_handle_s* h) {
@@ -70,10 +84,13 @@ static void release_streams(rcgp_handle_s* h) {
 
 static void free_all(rcgp_handle_s* h) {
   double** bufs[] = {&h->X, &h->Z, &h->sq, &h->y, &h->w, &h->alpha, &h->A, &h->Linv, &h->S, &h->invdiag, &h->logdiag, &h->partial,
-                     &h->scal, &h->ell_d, &h->FS_d, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob, &h->gV, &h->gC};
+                     &h->scal, &h->ell_d, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob, &h->gV, &h->gC};
   for (auto b : bufs)
     if (*b) { hipFree(*b); *b = nullptr; }
-  if (h->info) { hipFree(h->info); h->info = nullptr; }
+  h->info = nullptr;                                       // (inside scal)
+  h->FS_d = nullptr;                                       // (inside ell_d's allocation)
+  if (h->pin) { (void)hipHostFree(h->pin); h->pin = nullptr; }
+  if (h->ev_hyper) { (void)hipEventDestroy(h->ev_hyper); h->ev_hyper = nullptr; }
   for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
   h->prof_events.clear();
   for (auto& e : h->event_pool) (void)hipEventDestroy(e);
@@ -213,10 +230,16 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   RC_HIP(hipMalloc(&h->A, (size_t)Np * Np * sizeof(double)));
   RC_HIP(hipMalloc(&h->invdiag, (size_t)Np * 128 * sizeof(double)));
   RC_HIP(hipMalloc(&h->logdiag, (size_t)Np * sizeof(double)));
-  RC_HIP(hipMalloc(&h->scal, 256 * sizeof(double)));
-  RC_HIP(hipMalloc(&h->info, sizeof(int)));
-  RC_HIP(hipMalloc(&h->ell_d, (size_t)h->L * M * sizeof(double)));
-  RC_HIP(hipMalloc(&h->FS_d, (size_t)2 * h->L * h->L * sizeof(double)));
+  RC_HIP(hipMalloc(&h->scal, RC_SCAL_ELEMS * sizeof(double)));
+  RC_HIP(hipMemsetAsync(h->scal, 0, RC_SCAL_ELEMS * sizeof(double), h->stream));
+  h->info = reinterpret_cast<int*>(h->scal + RC_SCAL_INFO);
+  const size_t n_hyper = (size_t)h->L * M + (size_t)2 * h->L * h->L;
+  RC_HIP(hipMalloc(&h->ell_d, n_hyper * sizeof(double)));                  // ell, then F and Sigma: one upload per hyper-parameter change
+  h->FS_d = h->ell_d + (size_t)h->L * M;
+  h->pin_result = (n_hyper + 7) / 8 * 8;
+  h->pin_elems = h->pin_result + RC_SCAL_ELEMS + (size_t)(h->L * (h->L + 1) / 2) * (2 * M + 2);
+  RC_HIP(hipHostMalloc(&h->pin, h->pin_elems * sizeof(double), hipHostMallocDefault));
+  RC_HIP(hipEventCreateWithFlags(&h->ev_hyper, hipEventDisableTiming));
   int rc;
   for (int l = 0; l < h->L; ++l)                                   // the same inputs under every output block
     if ((rc = upload_padded(h, h->X + (size_t)l * h->Nb * M, X, h->N, h->Nb, M))) return rc;
@@ -261,7 +284,7 @@ RC_API int rcgp_create(rcgp_handle* out, int device, int64_t N, int M, const dou
 RC_API int rcgp_destroy(rcgp_handle h) {
   if (!h) return -1;
   hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  join_streams(h);                                         // all six, not just the main one: nothing of this handle is in flight below
   free_all(h);
   delete h;
   return 0;
@@ -275,16 +298,19 @@ RC_API int rcgp_set_y(rcgp_handle h, const double* y) {
   return rc;
 }
 
+// One asynchronous copy from pinned memory, no stream synchronisation: the evaluation that follows is ordered behind it on the main
+// stream. The staging block is rewritten only after the previous upload has left it (an event that has long completed by then).
 static int upload_hyper(rcgp_handle_s* h) {
-  const size_t LL = (size_t)h->L * h->L;
-  std::vector<double> fs(2 * LL);
-  memcpy(fs.data(), h->Fm.data(), LL * sizeof(double));
-  memcpy(fs.data() + LL, h->Sm.data(), LL * sizeof(double));
-  RC_HIP(hipMemcpyAsync(h->ell_d, h->ell.data(), h->ell.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  RC_HIP(hipMemcpyAsync(h->FS_d, fs.data(), fs.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  RC_HIP(hipStreamSynchronize(h->stream));
+  const size_t LL = (size_t)h->L * h->L, LM = h->ell.size();
+  if (h->hyper_in_flight) { RC_HIP(hipEventSynchronize(h->ev_hyper)); h->hyper_in_flight = false; }
+  memcpy(h->pin, h->ell.data(), LM * sizeof(double));
+  memcpy(h->pin + LM, h->Fm.data(), LL * sizeof(double));
+  memcpy(h->pin + LM + LL, h->Sm.data(), LL * sizeof(double));
+  RC_HIP(hipMemcpyAsync(h->ell_d, h->pin, (LM + 2 * LL) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RC_HIP(hipEventRecord(h->ev_hyper, h->stream));
+  h->hyper_in_flight = true;
   h->hyper_set = true;
-  h->factored = h->inverted = false;
+  h->factored = h->inverted = h->gram_fresh = false;
   return 0;
 }
 
@@ -348,6 +374,7 @@ static int do_gram(rcgp_handle_s* h) {
   if ((rc = rc_launch_scale(h))) return rc;
   if ((rc = rc_launch_gram(h))) return rc;
   h->factored = h->inverted = false;
+  h->gram_fresh = true;
   return 0;
 }
 
@@ -378,6 +405,12 @@ RC_API int rcgp_stage_gram(rcgp_handle h) {
 
 RC_API int rcgp_stage_potrf(rcgp_handle h) {
   RC_CHECK_H(h);
+  int rc;
+  if ((rc = need_hyper(h))) return rc;
+  if (!h->gram_fresh) {                       // A holds a factor (or nothing): factoring it again would silently produce garbage
+    h->err = "rcgp_stage_potrf: no fresh Gram matrix (call rcgp_stage_gram first; a factorisation consumes it)";
+    return -5;
+  }
   h->tt_active = false;
   return rc_potrf(h);
 }
@@ -413,7 +446,8 @@ RC_API int rcgp_lml_grad_mo(rcgp_handle h, double* lml, double* g_ell, double* g
   if ((rc = ensure_factor(h, true))) return rc;
   int nrows = 0;
   if ((rc = rc_launch_grad_mo(h, &nrows))) return rc;
-  if ((rc = rc_lml_value(h, lml))) return rc;
+  if ((rc = rc_grad_queue_mo(h))) return rc;
+  if ((rc = rc_lml_value(h, lml))) return rc;            // the one host synchronisation of an evaluation
   return rc_grad_finish_mo(h, g_ell, g_F, g_Sigma);
 }
 
@@ -424,9 +458,10 @@ RC_API int rcgp_lml_grad(rcgp_handle h, double* lml, double* grad) {
   int rc;
   if ((rc = ensure_factor(h, true))) return rc;
   int nrows = 0;
-  if ((rc = rc_launch_grad(h, &nrows))) return rc;          // queued behind the factorisation: one host sync per evaluation
-  if ((rc = rc_lml_value(h, lml))) return rc;
-  return rc_grad_finish(h, nrows, grad);
+  if ((rc = rc_launch_grad(h, &nrows))) return rc;          // queued behind the factorisation
+  if ((rc = rc_grad_queue(h, nrows))) return rc;
+  if ((rc = rc_lml_value(h, lml))) return rc;               // the one host synchronisation of an evaluation
+  return rc_grad_finish(h, grad);
 }
 
 RC_API int rcgp_factor(rcgp_handle h) {
@@ -513,6 +548,38 @@ int rc_ensure_pred(rcgp_handle_s* h) {
   RC_HIP(hipMalloc(&h->pmean, (size_t)PRED_CAP * sizeof(double)));
   RC_HIP(hipMalloc(&h->pvar, (size_t)PRED_CAP * sizeof(double)));
   h->pred_cap = PRED_CAP;
+  h->pts_cap = PRED_CAP;
+  return 0;
+}
+
+// Room for `pts` new points in Xs / Zs / sqs (the prediction path itself never needs more than PRED_CAP at a time).
+static int ensure_points(rcgp_handle_s* h, int64_t pts) {
+  int rc;
+  if ((rc = rc_ensure_pred(h))) return rc;
+  if (pts <= h->pts_cap) return 0;
+  RC_HIP(hipStreamSynchronize(h->stream));
+  double** bufs[] = {&h->Xs, &h->Zs, &h->sqs};
+  for (auto b : bufs) { RC_HIP(hipFree(*b)); *b = nullptr; }
+  h->pts_cap = 0;
+  RC_HIP(hipMalloc(&h->Xs, (size_t)pts * h->M * sizeof(double)));
+  RC_HIP(hipMalloc(&h->Zs, (size_t)pts * h->M * sizeof(double)));
+  RC_HIP(hipMalloc(&h->sqs, (size_t)pts * sizeof(double)));
+  h->pts_cap = pts;
+  return 0;
+}
+
+// Scratch of the gradient GP: V (Np x rows) and `blocks` products V^T V (rows x rows).
+static int ensure_gradient_scratch(rcgp_handle_s* h, int64_t rows_padded, int blocks) {
+  if (h->g_rows >= rows_padded && h->g_blocks >= blocks) return 0;
+  RC_HIP(hipStreamSynchronize(h->stream));
+  if (h->gV) { RC_HIP(hipFree(h->gV)); h->gV = nullptr; }
+  if (h->gC) { RC_HIP(hipFree(h->gC)); h->gC = nullptr; }
+  h->g_rows = 0;
+  h->g_blocks = 0;
+  RC_HIP(hipMalloc(&h->gV, (size_t)h->Np * rows_padded * sizeof(double)));
+  RC_HIP(hipMalloc(&h->gC, (size_t)blocks * rows_padded * rows_padded * sizeof(double)));
+  h->g_rows = rows_padded;
+  h->g_blocks = blocks;
   return 0;
 }
 
@@ -568,9 +635,9 @@ RC_API int rcgp_predict(rcgp_handle h, int64_t n, const double* Xnew, int includ
 // D[(o*M + m)][n] = d k(X_n, x_o) / d x_om = -(x_om - X_nm) / ell_m^2 * k(X_n, x_o)   (zero on the padding)
 __global__ void k_dkernel_rows(const double* __restrict__ Zs, const double* __restrict__ sqs, const double* __restrict__ Z,
                                const double* __restrict__ sq, const double* __restrict__ ell, int64_t n_pts, int64_t N, int64_t Np, int M,
-                               double var, double* __restrict__ D) {
+                               double var, double* __restrict__ D, int64_t row0) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t r = blockIdx.y;
+  const int64_t r = row0 + blockIdx.y;                      // row of the whole derivative matrix; D holds the chunk starting at row0
   if (n >= Np) return;
   const int64_t o = r / M;
   const int m = (int)(r - o * M);
@@ -581,7 +648,7 @@ __global__ void k_dkernel_rows(const double* __restrict__ Zs, const double* __re
     const double k = var * exp(sqs[o] + sq[n] + dot);
     v = -(Zs[o * M + m] - Z[n * M + m]) / ell[m] * k;              // (x - X)/ell^2 = (z - Z)/ell
   }
-  D[r * Np + n] = v;
+  D[(r - row0) * Np + n] = v;
 }
 
 RC_API int rcgp_predict_gradient(rcgp_handle h, int64_t n, const double* Xnew, double* mean, double* cov) {
@@ -590,32 +657,36 @@ RC_API int rcgp_predict_gradient(rcgp_handle h, int64_t n, const double* Xnew, d
   const int M = h->M;
   if (n < 1 || !Xnew || !mean || !cov) { h->err = "rcgp_predict_gradient: bad argument"; return -2; }
   const int64_t rows = n * M, rows_padded = ((rows + 127) / 128) * 128;
-  if (rows_padded > PRED_CAP) { h->err = "rcgp_predict_gradient: n * M exceeds 4096 (the covariance has (n M)^2 entries)"; return -6; }
   int rc;
   if ((rc = rcgp_factor(h))) return rc;
-  if ((rc = rc_ensure_pred(h))) return rc;
-  const int64_t Np = h->Np;
-  if (h->g_rows < rows_padded) {
-    if (h->gV) { RC_HIP(hipFree(h->gV)); h->gV = nullptr; }
-    if (h->gC) { RC_HIP(hipFree(h->gC)); h->gC = nullptr; }
-    RC_HIP(hipMalloc(&h->gV, (size_t)Np * rows_padded * sizeof(double)));
-    RC_HIP(hipMalloc(&h->gC, (size_t)rows_padded * rows_padded * sizeof(double)));
-    h->g_rows = rows_padded;
-    h->g_blocks = 1;
-  }
   const int64_t np = ((n + 127) / 128) * 128;
+  if ((rc = ensure_points(h, np))) return rc;
+  if ((rc = ensure_gradient_scratch(h, rows_padded, 1))) return rc;
+  const int64_t Np = h->Np;
   if ((rc = upload_padded(h, h->Xs, Xnew, n, np, M))) return rc;
   if ((rc = rc_launch_scale_rows(h, h->Xs, h->Zs, h->sqs, np))) return rc;
-  {
-    RcProfScope ps(h, RC_K_MISC, 0.0);
-    hipLaunchKernelGGL(k_dkernel_rows, dim3((unsigned)((Np + 255) / 256), (unsigned)rows_padded), dim3(256), 0, h->stream, h->Zs, h->sqs, h->Z,
-                       h->sq, h->ell_d, n, h->N, Np, M, h->var, h->KsT);
-    RC_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_rowdot, dim3((unsigned)rows), dim3(256), 0, h->stream, h->KsT, Np, h->alpha, Np, h->pmean);
-    RC_HIP(hipGetLastError());
+  // the (n M) derivative rows pass through KsT PRED_CAP at a time (the reference forms them all at once by tape.jacobian,
+  // gpr/models.py:407-410): mean chunk by chunk, V = L^-1 D^T column block by column block, then one V^T V over all of them
+  for (int64_t r0 = 0; r0 < rows_padded; r0 += PRED_CAP) {
+    const int64_t rc_rows = (rows_padded - r0 < PRED_CAP) ? rows_padded - r0 : PRED_CAP;
+    const int64_t live = (rows - r0 < rc_rows) ? rows - r0 : rc_rows;
+    {
+      RcProfScope ps(h, RC_K_MISC, 0.0);
+      hipLaunchKernelGGL(k_dkernel_rows, dim3((unsigned)((Np + 255) / 256), (unsigned)rc_rows), dim3(256), 0, h->stream, h->Zs, h->sqs, h->Z, h->sq,
+                         h->ell_d, n, h->N, Np, M, h->var, h->KsT, r0);
+      RC_HIP(hipGetLastError());
+      if (live > 0) {
+        hipLaunchKernelGGL(k_rowdot, dim3((unsigned)live), dim3(256), 0, h->stream, h->KsT, Np, h->alpha, Np, h->pmean);
+        RC_HIP(hipGetLastError());
+      }
+    }
+    if ((rc = rc_launch_linv_rows(h, rc_rows, h->gV, rows_padded, r0))) return rc;
+    if (live > 0) {
+      RC_HIP(hipMemcpyAsync(mean + r0, h->pmean, (size_t)live * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      RC_HIP(hipStreamSynchronize(h->stream));              // pmean and KsT are rewritten by the next chunk
+    }
   }
-  if ((rc = rc_launch_gradient_cov(h, rows_padded, h->gV, h->gC))) return rc;
-  RC_HIP(hipMemcpyAsync(mean, h->pmean, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if ((rc = rc_launch_vtv(h, rows_padded, h->gV, h->gC))) return rc;
   RC_HIP(hipMemcpy2DAsync(cov, (size_t)rows * sizeof(double), h->gC, (size_t)rows_padded * sizeof(double), (size_t)rows * sizeof(double),
                           (size_t)rows, hipMemcpyDeviceToHost, h->stream));
   RC_HIP(hipStreamSynchronize(h->stream));
@@ -626,9 +697,9 @@ RC_API int rcgp_predict_gradient(rcgp_handle h, int64_t n, const double* Xnew, d
 // U = X_N / ell_Lb and u = x_o / ell_l (Zs holds the L * n scaled points output-major); zero on the padding.
 __global__ void k_dkernel_rows_mo(const double* __restrict__ Zs, const double* __restrict__ sqs, const double* __restrict__ Z,
                                   const double* __restrict__ sq, const double* __restrict__ ell, const double* __restrict__ F, int L,
-                                  int64_t n_pts, int64_t N, int64_t Nb, int64_t Np, int M, double* __restrict__ D) {
+                                  int64_t n_pts, int64_t N, int64_t Nb, int64_t Np, int M, double* __restrict__ D, int64_t row0) {
   const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t r = blockIdx.y;
+  const int64_t r = row0 + blockIdx.y;
   if (a >= Np) return;
   const int64_t p = r / M;                                 // scaled point (l, o)
   const int m = (int)(r - p * M);
@@ -641,7 +712,7 @@ __global__ void k_dkernel_rows_mo(const double* __restrict__ Zs, const double* _
     const double k = F[Lb * L + l] * exp(sqs[p] + sq[a] + dot);
     v = -(Zs[p * M + m] - Z[a * M + m]) / ell[l * M + m] * k;
   }
-  D[r * Np + a] = v;
+  D[(r - row0) * Np + a] = v;
 }
 
 RC_API int rcgp_predict_gradient_mo(rcgp_handle h, int64_t n, const double* Xnew, double* mean, double* cov) {
@@ -649,32 +720,35 @@ RC_API int rcgp_predict_gradient_mo(rcgp_handle h, int64_t n, const double* Xnew
   const int M = h->M, L = h->L;
   if (n < 1 || !Xnew || !mean || !cov) { h->err = "rcgp_predict_gradient_mo: bad argument"; return -2; }
   const int64_t rows = (int64_t)L * n * M, rows_padded = ((rows + 127) / 128) * 128;
-  if (rows_padded > PRED_CAP) { h->err = "rcgp_predict_gradient_mo: L * n * M exceeds 4096"; return -6; }
   int rc;
   if ((rc = rcgp_factor(h))) return rc;
-  if ((rc = rc_ensure_pred(h))) return rc;
+  if ((rc = ensure_points(h, (int64_t)L * n))) return rc;
+  if ((rc = ensure_gradient_scratch(h, rows_padded, L))) return rc;
   const int64_t Np = h->Np;
-  if (h->g_rows < rows_padded || h->g_blocks < L) {
-    if (h->gV) { RC_HIP(hipFree(h->gV)); h->gV = nullptr; }
-    if (h->gC) { RC_HIP(hipFree(h->gC)); h->gC = nullptr; }
-    RC_HIP(hipMalloc(&h->gV, (size_t)Np * rows_padded * sizeof(double)));
-    RC_HIP(hipMalloc(&h->gC, (size_t)L * rows_padded * rows_padded * sizeof(double)));
-    h->g_rows = rows_padded;
-    h->g_blocks = L;
-  }
   if ((rc = upload_padded(h, h->Xs, Xnew, n, n, M))) return rc;
+  // the L scaled copies of the points, output-major: Zs block l = x / ell_l
   for (int l = 0; l < L; ++l)
     if ((rc = rc_launch_scale_rows(h, h->Xs, h->Zs + (size_t)l * n * M, h->sqs + (size_t)l * n, n, l))) return rc;
-  {
-    RcProfScope ps(h, RC_K_MISC, 0.0);
-    hipLaunchKernelGGL(k_dkernel_rows_mo, dim3((unsigned)((Np + 255) / 256), (unsigned)rows_padded), dim3(256), 0, h->stream, h->Zs, h->sqs, h->Z,
-                       h->sq, h->ell_d, h->FS_d, L, n, h->N, h->Nb, Np, M, h->KsT);
-    RC_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_rowdot, dim3((unsigned)rows), dim3(256), 0, h->stream, h->KsT, Np, h->alpha, Np, h->pmean);
-    RC_HIP(hipGetLastError());
+  for (int64_t r0 = 0; r0 < rows_padded; r0 += PRED_CAP) {
+    const int64_t rc_rows = (rows_padded - r0 < PRED_CAP) ? rows_padded - r0 : PRED_CAP;
+    const int64_t live = (rows - r0 < rc_rows) ? rows - r0 : rc_rows;
+    {
+      RcProfScope ps(h, RC_K_MISC, 0.0);
+      hipLaunchKernelGGL(k_dkernel_rows_mo, dim3((unsigned)((Np + 255) / 256), (unsigned)rc_rows), dim3(256), 0, h->stream, h->Zs, h->sqs, h->Z,
+                         h->sq, h->ell_d, h->FS_d, L, n, h->N, h->Nb, Np, M, h->KsT, r0);
+      RC_HIP(hipGetLastError());
+      if (live > 0) {
+        hipLaunchKernelGGL(k_rowdot, dim3((unsigned)live), dim3(256), 0, h->stream, h->KsT, Np, h->alpha, Np, h->pmean);
+        RC_HIP(hipGetLastError());
+      }
+    }
+    if ((rc = rc_launch_linv_rows(h, rc_rows, h->gV, rows_padded, r0))) return rc;
+    if (live > 0) {
+      RC_HIP(hipMemcpyAsync(mean + r0, h->pmean, (size_t)live * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      RC_HIP(hipStreamSynchronize(h->stream));
+    }
   }
-  if ((rc = rc_launch_gradient_cov(h, rows_padded, h->gV, h->gC, true))) return rc;
-  RC_HIP(hipMemcpyAsync(mean, h->pmean, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if ((rc = rc_launch_vtv(h, rows_padded, h->gV, h->gC, true))) return rc;
   for (int b = 0; b < L; ++b)
     RC_HIP(hipMemcpy2DAsync(cov + (size_t)b * rows * rows, (size_t)rows * sizeof(double), h->gC + (size_t)b * rows_padded * rows_padded,
                             (size_t)rows_padded * sizeof(double), (size_t)rows * sizeof(double), (size_t)rows, hipMemcpyDeviceToHost, h->stream));

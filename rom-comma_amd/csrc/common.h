@@ -13,6 +13,8 @@
 #define RC_MAX_M 64            // largest input dimensionality supported by the fused kernels
 #define RC_MAX_L 16            // most outputs of one covariant GP
 #define RC_RESERVE_CUS_DEFAULT 0   // CUs the bulk-update stream leaves to the panel chain (RCGP_RESERVE_CUS); 0 = no CU mask
+#define RC_SCAL_ELEMS 256      // h->scal: [0,2) LML sums, [8, 8+M+2) gradient sums, [RC_SCAL_INFO] the Cholesky status word
+#define RC_SCAL_INFO 128
 #define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -75,6 +77,7 @@ struct rcgp_handle_s {
   double var = 1.0, noise = 0.0;
   bool hyper_set = false;
   // state flags
+  bool gram_fresh = false;     // A holds the Gram matrix of the current hyper-parameters, not yet factored (rcgp_stage_potrf needs it)
   bool factored = false;       // A holds L (lower), w = L^-1 y, logdiag valid
   bool inverted = false;       // Linv holds L^-1, alpha valid
   // device buffers
@@ -92,12 +95,17 @@ struct rcgp_handle_s {
   double *partial = nullptr;   // scratch for two-stage reductions
   size_t partial_elems = 0;
   double *scal = nullptr;      // small device scalars/vectors for results
-  int *info = nullptr;         // device: 0 ok, k>0 = leading minor k not positive definite
-  double *ell_d = nullptr;     // device copy of ell (L x M)
-  double *FS_d = nullptr;      // device copies of Fm then Sm (2 x L x L)
+  int *info = nullptr;         // device: 0 ok, k>0 = leading minor k not positive definite (lives inside scal: one copy fetches both)
+  double *ell_d = nullptr;     // device copy of ell (L x M), followed in the same allocation by
+  double *FS_d = nullptr;      // ... the device copies of Fm then Sm (2 x L x L)
+  double *pin = nullptr;       // pinned host staging: [0, pin_result) hyper-parameters going up, [pin_result, ...) results coming down
+  size_t pin_elems = 0, pin_result = 0;   // (pin_result: first element of the result block)
+  hipEvent_t ev_hyper = nullptr;   // the last hyper-parameter upload has left the staging buffer
+  bool hyper_in_flight = false;
   // predict scratch
   double *Xs = nullptr, *Zs = nullptr, *sqs = nullptr, *KsT = nullptr, *pmean = nullptr, *pvar = nullptr;
-  int64_t pred_cap = 0;
+  int64_t pred_cap = 0;        // rows of KsT / pmean / pvar
+  int64_t pts_cap = 0;         // points Xs / Zs / sqs hold (>= pred_cap; predict_gradient grows it)
   double *gV = nullptr, *gC = nullptr;   // predict_gradient scratch
   int64_t g_rows = 0;
   int g_blocks = 0;                       // V^T V products gC has room for
@@ -199,8 +207,9 @@ int rc_launch_grad_mo(rcgp_handle_s* h, int* nrows);     // covariant GP: 2M + 2
 // predict: colsum((Linv * Ks)^2) for np test points -> h->pvar (np)
 int rc_launch_predict_var(rcgp_handle_s* h, int64_t np);
 
-// predict_gradient: V (Np x rows) = Linv * KsT^T stored, C (rows x rows) = V^T V
-int rc_launch_gradient_cov(rcgp_handle_s* h, int64_t rows_padded, double* V, double* C, bool per_block = false);
+// predict_gradient: V (Np x rows) = Linv * D^T stored chunk by chunk (the chunk's rows of D sit in KsT), then C (rows x rows) = V^T V
+int rc_launch_linv_rows(rcgp_handle_s* h, int64_t rows_chunk, double* V, int64_t ldv, int64_t col0);
+int rc_launch_vtv(rcgp_handle_s* h, int64_t rows_padded, const double* V, double* C, bool per_block = false);
 
 // ---- potrf.hip
 int rc_potrf(rcgp_handle_s* h);                              // blocked Cholesky of A in place, w = L^-1 y, logdiag
@@ -215,7 +224,9 @@ int rc_lml_value(rcgp_handle_s* h, double* lml);             // from logdiag and
 int rc_sobol_weight_sum(rcgp_handle_s* h, const double* phi, double pre, const double* alpha_host, double* sum);
 int rc_sobol_pair(rcgp_handle_s* h, const double* phi_a, double pre_a, const double* alpha_a, double shift_a, const double* phi_b,
                   double pre_b, const double* alpha_b, double shift_b, int n_slices, const int32_t* slices, double* V_host);
-int rc_grad_finish(rcgp_handle_s* h, int nrows, double* grad);
+int rc_grad_queue(rcgp_handle_s* h, int nrows);              // queue the gradient's final reduction (before rc_lml_value)
+int rc_grad_finish(rcgp_handle_s* h, double* grad);          // host: gradient from the pinned result block (after rc_lml_value)
+int rc_grad_queue_mo(rcgp_handle_s* h);
 int rc_grad_finish_mo(rcgp_handle_s* h, double* g_ell, double* g_F, double* g_S);
 
 // ---- sobol.hip

@@ -902,16 +902,22 @@ __global__ void RC_BOUNDS(WN) k_vtv(const double* __restrict__ V, int64_t ldv, i
   acc_store<WN>(acc, C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128, ldc);
 }
 
+// V[:, col0 : col0 + rows_chunk) = Linv * D^T for the chunk of derivative rows currently in KsT (rows_chunk a multiple of 128); V is
+// Np x ldv row-major. predict_gradient feeds the rows through KsT 4096 at a time, so the number of gradient components is bounded by
+// memory only.
+int rc_launch_linv_rows(rcgp_handle_s* h, int64_t rows_chunk, double* V, int64_t ldv, int64_t col0) {
+  const int64_t T = h->Np / 128, R = rows_chunk / 128;
+  RcProfScope ps(h, RC_K_GEMM, (double)h->Np * (double)h->Np * (double)rows_chunk);
+  hipLaunchKernelGGL(k_linv_times_rows<RC_WN>, dim3((unsigned)R, (unsigned)T), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->KsT, h->Np,
+                     V + col0, ldv);
+  RC_HIP(hipGetLastError());
+  return 0;
+}
+
 // C = V^T V over all rows of V; with per_block one product per output block of rows (a covariant GP's predict_gradient keeps
 // the training output index, gpr/models.py:398: 'LNlOM, LNlom -> OLolMm'), stored one after the other in C.
-int rc_launch_gradient_cov(rcgp_handle_s* h, int64_t rows_padded, double* V, double* C, bool per_block) {
-  const int64_t T = h->Np / 128, R = rows_padded / 128;
-  {
-    RcProfScope ps(h, RC_K_GEMM, (double)h->Np * (double)h->Np * (double)rows_padded);
-    hipLaunchKernelGGL(k_linv_times_rows<RC_WN>, dim3((unsigned)R, (unsigned)T), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->KsT, h->Np, V,
-                       rows_padded);
-    RC_HIP(hipGetLastError());
-  }
+int rc_launch_vtv(rcgp_handle_s* h, int64_t rows_padded, const double* V, double* C, bool per_block) {
+  const int64_t R = rows_padded / 128;
   const int nprod = per_block ? h->L : 1;
   const int64_t span = per_block ? h->Nb : h->Np;
   for (int b = 0; b < nprod; ++b) {

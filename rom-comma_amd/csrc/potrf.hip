@@ -765,6 +765,7 @@ int rc_potrf(rcgp_handle_s* h) {
   h->la_cursor = 0;
   const bool fine = la && h->fine_chain;
   if (inv && (rc = rc_trtri_begin(h))) return rc;
+  h->gram_fresh = false;                                           // consumed, whatever happens below
   if (fine) {
     if ((rc = potrf_fine(h, inv))) return rc;
     h->factored = true;

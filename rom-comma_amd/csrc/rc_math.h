@@ -4,7 +4,7 @@
 
 // exp(x) in fp64: k = rint(x log2 e); r = x - k ln2 (two-term Cody-Waite); degree-13 Taylor polynomial on |r| <= 0.3466
 // (truncation 4e-18 relative); scaled by 2^k with v_ldexp_f64. Measured max error vs the correctly rounded result < 1 ulp
-// on [-745, 709] (tests/test_gpu_kernels.py::test_exp_accuracy). Underflows to 0 below -745.2, overflows to +inf above 709.8.
+// on [-745, 709] (tests/test_gpu_parity.py::test_exp_accuracy_through_gram). Underflows to 0 below -745.2, overflows to +inf above 709.8.
 __device__ __forceinline__ double rc_exp(double x) {
   const double LOG2E = 1.4426950408889634074;
   const double LN2_HI = 6.93147180369123816490e-01;   // high 33 bits of ln 2

@@ -8,6 +8,7 @@
 // VALU-bound (fp64 exp), traffic ~ 2 N M doubles per tile from L2: no HBM roofline applies.
 #include "common.h"
 #include "rc_math.h"
+#include <algorithm>
 #include <limits>
 
 #define XST 130
@@ -430,15 +431,21 @@ int rc_sobol_pair(rcgp_handle_s* h, const double* phi_a, double pre_a, const dou
 // with per-dimension coefficients computed on the host.
 // =====================================================================================================================
 
-// u partials: partial[(ti * 3M + s) * Np + n] = sum over the rows of row-tile ti of gl[N] * prod_{m in slice s} h_m(N, n), for
-// the canonical slices (first-order m, closed [0,m+1), complement [m+1,M)). Same tile/thread layout as k_sobol_pairs.
+// u partials: partial[(ti * nS + s) * Np + n] = sum over the rows of row-tile ti of gl[N] * prod_{m in slice s} h_m(N, n). Same
+// tile/thread layout as k_sobol_pairs.
+// mode 0: the canonical slices (index m: first-order [m,m+1); M + m: closed [0,m+1); 2M + m: complement [m+1,M)) with indices in the
+//         window [s_lo, s_hi), nS = s_hi - s_lo: all 3M in one pass when the column accumulators fit in LDS (M <= 29), otherwise the host
+//         walks the window over the 3M indices (the running exponent sums are rebuilt every pass, exponentials only where wanted);
+// mode 1: ONE arbitrary slice [ma, mb) (ClosedSobolWithError.marginalize takes any, gsa/calibrators.py:348-373), nS = 1.
 __global__ void __launch_bounds__(256) k_sobol_matvec(const double* __restrict__ X, const double* __restrict__ gl,
-                                                      const double* __restrict__ consts, int M, int64_t Np, double* __restrict__ partial) {
+                                                      const double* __restrict__ consts, int M, int64_t Np, double* __restrict__ partial,
+                                                      int mode, int ma, int mb, int s_lo, int s_hi) {
   extern __shared__ double sm[];
   double* xi = sm;                        // [M][XST] rows (N side)
   double* xj = sm + M * XST;              // [M][XST] columns (n side)
   double* slots = xj + M * XST;           // [4 waves][2 kinds][128]
-  double* colacc = slots + 4 * 2 * 128;   // [3M][128]
+  double* colacc = slots + 4 * 2 * 128;   // [nS][128]
+  const int nS = s_hi - s_lo;
   const int tj = blockIdx.x, ti = blockIdx.y;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   for (int e = t; e < 128 * M; e += 256) {
@@ -446,7 +453,7 @@ __global__ void __launch_bounds__(256) k_sobol_matvec(const double* __restrict__
     xi[m * XST + rr] = X[((int64_t)ti * 128 + rr) * M + m];
     xj[m * XST + rr] = X[((int64_t)tj * 128 + rr) * M + m];
   }
-  for (int e = t; e < 3 * M * 128; e += 256) colacc[e] = 0.0;
+  for (int e = t; e < nS * 128; e += 256) colacc[e] = 0.0;
   const int tx = t & 15, ty = t >> 4;
   double gi[8];
 #pragma unroll
@@ -462,35 +469,39 @@ __global__ void __launch_bounds__(256) k_sobol_matvec(const double* __restrict__
 #pragma unroll
     for (int c = 0; c < 8; ++c) e[a][c] = 0.0;
 
-  // one m-step: computes t_m, updates the running sums, returns per-column partial sums over this thread's rows
-  auto publish = [&](const double (&cf)[8], const double (&cc)[8], int nkinds, int idx0, int idx1) {
+  // per-column partial sums over this thread's rows -> column accumulators idx0 (kind 0, if want0) and idx1 (kind 1, if want1);
+  // want0 / want1 are uniform over the workgroup
+  auto publish = [&](const double (&cf)[8], const double (&cc)[8], bool want0, bool want1, int idx0, int idx1) {
+    if (!want0 && !want1) return;
     // reduce over the 4 row-groups of the wave (lanes differing in lane >> 4), then one slot per wave
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       double vf = cf[c], vc = cc[c];
       vf += __shfl_xor(vf, 16);
       vf += __shfl_xor(vf, 32);
-      if (nkinds > 1) {
-        vc += __shfl_xor(vc, 16);
-        vc += __shfl_xor(vc, 32);
-      }
+      vc += __shfl_xor(vc, 16);
+      vc += __shfl_xor(vc, 32);
       if ((lane >> 4) == 0) {
         const int col = 2 * tx + 32 * (c >> 1) + (c & 1);
         slots[(wave * 2 + 0) * 128 + col] = vf;
-        if (nkinds > 1) slots[(wave * 2 + 1) * 128 + col] = vc;
+        slots[(wave * 2 + 1) * 128 + col] = vc;
       }
     }
     __syncthreads();
-    if (t < 128 * nkinds) {
+    if (t < 256) {
       const int kind = t >> 7, col = t & 127;
-      const double sum = (slots[(0 * 2 + kind) * 128 + col] + slots[(1 * 2 + kind) * 128 + col]) +
-                         (slots[(2 * 2 + kind) * 128 + col] + slots[(3 * 2 + kind) * 128 + col]);
-      colacc[(kind == 0 ? idx0 : idx1) * 128 + col] += sum;          // a single owner thread per (slice, column): fixed order
+      if (kind == 0 ? want0 : want1) {
+        const double sum = (slots[(0 * 2 + kind) * 128 + col] + slots[(1 * 2 + kind) * 128 + col]) +
+                           (slots[(2 * 2 + kind) * 128 + col] + slots[(3 * 2 + kind) * 128 + col]);
+        colacc[(kind == 0 ? idx0 : idx1) * 128 + col] += sum;          // a single owner thread per (slice, column): fixed order
+      }
     }
     __syncthreads();
   };
+  auto in_window = [&](int idx) { return idx >= s_lo && idx < s_hi; };
 
-  for (int m = 0; m < M; ++m) {                                       // ascending: first-order [m,m+1) and closed [0,m+1)
+  // one m-step of the running exponent sums; cf / cc receive sum_rows gi exp(t_m) / gi exp(e) where wanted
+  auto step = [&](int m, bool want_f, bool want_c, double (&cf)[8], double (&cc)[8]) {
     const double k0 = c0[m], k2 = c2[m], kl = pl[m], kj = pj[m];
     double ai[8], ui[8], bj[8], xc[8];
 #pragma unroll
@@ -507,7 +518,6 @@ __global__ void __launch_bounds__(256) k_sobol_matvec(const double* __restrict__
       bj[2 * b] = kj * x.x * x.x;
       bj[2 * b + 1] = kj * x.y * x.y;
     }
-    double cf[8], cc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { cf[c] = 0.0; cc[c] = 0.0; }
 #pragma unroll
@@ -516,47 +526,40 @@ __global__ void __launch_bounds__(256) k_sobol_matvec(const double* __restrict__
       for (int c = 0; c < 8; ++c) {
         const double tm = fma(ui[a], xc[c], ai[a] + bj[c]);
         e[a][c] += tm;
-        cf[c] = fma(gi[a], rc_exp(tm), cf[c]);
-        cc[c] = fma(gi[a], rc_exp(e[a][c]), cc[c]);
+        if (want_f) cf[c] = fma(gi[a], rc_exp(tm), cf[c]);
+        if (want_c) cc[c] = fma(gi[a], rc_exp(e[a][c]), cc[c]);
       }
-    publish(cf, cc, 2, m, M + m);
-  }
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) e[a][c] = 0.0;
-  for (int m = M - 1; m >= 1; --m) {                                  // descending: complements [m, M) -> index 2M + m - 1
-    const double k0 = c0[m], k2 = c2[m], kl = pl[m], kj = pj[m];
-    double ai[8], ui[8], bj[8], xc[8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      const double x = xi[m * XST + ty + 16 * a];
-      ai[a] = fma(kl * x, x, k0);
-      ui[a] = k2 * x;
+  };
+
+  double cf[8], cc[8];
+  if (mode != 0) {                                                      // one generic slice: the exponent sum over [ma, mb), one exp
+    for (int m = ma; m < mb; ++m) step(m, false, m == mb - 1, cf, cc);
+    publish(cc, cc, true, false, 0, 0);
+  } else {
+    int last_asc = -1;                                                  // no need to walk past the last wanted ascending index
+    for (int m = 0; m < M; ++m)
+      if (in_window(m) || in_window(M + m)) last_asc = m;
+    for (int m = 0; m <= last_asc; ++m) {                               // ascending: first-order [m,m+1) and closed [0,m+1)
+      const bool wf = in_window(m), wc = in_window(M + m);
+      step(m, wf, wc, cf, cc);
+      publish(cf, cc, wf, wc, m - s_lo, M + m - s_lo);
     }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const double2 x = *reinterpret_cast<const double2*>(xj + m * XST + 2 * tx + 32 * b);
-      xc[2 * b] = x.x;
-      xc[2 * b + 1] = x.y;
-      bj[2 * b] = kj * x.x * x.x;
-      bj[2 * b + 1] = kj * x.y * x.y;
-    }
-    double cf[8], cc[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { cf[c] = 0.0; cc[c] = 0.0; }
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        e[a][c] += fma(ui[a], xc[c], ai[a] + bj[c]);
-        cf[c] = fma(gi[a], rc_exp(e[a][c]), cf[c]);
-      }
-    publish(cf, cc, 1, 2 * M + m - 1, 0);
+      for (int c = 0; c < 8; ++c) e[a][c] = 0.0;
+    int last_desc = M;                                                  // smallest m whose complement index is wanted
+    for (int m = M - 1; m >= 1; --m)
+      if (in_window(2 * M + m - 1)) last_desc = m;
+    for (int m = M - 1; m >= last_desc; --m) {                          // descending: complements [m, M) -> index 2M + m - 1
+      const bool wt = in_window(2 * M + m - 1);
+      step(m, false, wt, cf, cc);
+      publish(cc, cc, wt, false, 2 * M + m - 1 - s_lo, 0);
+    }
   }
-  for (int idx = t; idx < 3 * M * 128; idx += 256) {
-    const int s = idx >> 7, col = idx & 127;
-    partial[((int64_t)ti * 3 * M + s) * Np + (int64_t)tj * 128 + col] = colacc[idx];
+  for (int idx = t; idx < nS * 128; idx += 256) {
+    const int sidx = idx >> 7, col = idx & 127;
+    partial[((int64_t)ti * nS + sidx) * Np + (int64_t)tj * 128 + col] = colacc[idx];
   }
 }
 
@@ -585,19 +588,19 @@ __global__ void k_sobol_gtilde(const double* __restrict__ X, const double* __res
   out[i] = v;
 }
 
-// F rows for the psi terms (row-major [rows][Np] into KsT): r < 3M: g0 * u_r ; 3M <= r < 6M: g0 * (u_{r-3M} + u_full) ;
-// r == 6M: g0 * u_full_bb (the (b,b) full-model vector when a != b, else a copy of row `full`) ; zero beyond.
+// F rows for the psi terms (row-major [rows][Np] into KsT) from R vectors u_r: r < R: g0 * u_r ; R <= r < 2R: g0 * (u_{r-R} + u_full) ;
+// r == 2R: g0 * u_full, where u_full is the (b,b) full-model vector ; zero beyond.
 // F has leading dimension ldf and the row lands at column offset off: a covariant GP embeds the vector in its output block of the
 // (L N) system, zeros elsewhere (the set_diag / reshape of gsa/calibrators.py:304-306 for a rank-2 K_cho).
 __global__ void k_sobol_psi_rows(const double* __restrict__ U, const double* __restrict__ Ufull, const double* __restrict__ g0,
-                                 int M, int64_t Np, int64_t rows_padded, double* __restrict__ F, int64_t ldf, int64_t off) {
+                                 int R, int64_t Np, int64_t rows_padded, double* __restrict__ F, int64_t ldf, int64_t off) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
   if (n >= Np) return;
   double v = 0.0;
-  if (r < 3 * M) v = g0[n] * U[(int64_t)r * Np + n];
-  else if (r < 6 * M) v = g0[n] * (U[(int64_t)(r - 3 * M) * Np + n] + Ufull[n]);
-  else if (r == 6 * M) v = g0[n] * Ufull[n];
+  if (r < R) v = g0[n] * U[(int64_t)r * Np + n];
+  else if (r < 2 * R) v = g0[n] * (U[(int64_t)(r - R) * Np + n] + Ufull[n]);
+  else if (r == 2 * R) v = g0[n] * Ufull[n];
   F[(int64_t)r * ldf + off + n] = v;
 }
 
@@ -618,11 +621,10 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
     ell_a = h->ell.data() + (size_t)out_a * M;
     var_a = h->Fm[(size_t)out_a * h->L + out_a];
   }
-  if (M > 29) { h->err = "sobol errors: at most 29 input dimensions are supported"; return -6; }
+  auto is_canonical = [M](int a, int b) { return a == b || b == a + 1 || a == 0 || b == M; };
   for (int s = 0; s < n_slices; ++s) {
     const int a = slices[2 * s], b = slices[2 * s + 1];
     if (a < 0 || b > M || a > b) { h->err = "sobol errors: bad slice"; return -2; }
-    if (!(a == b || b == a + 1 || a == 0 || b == M)) { h->err = "sobol errors: only first-order, closed and total slices are supported"; return -6; }
   }
   int rc;
   if ((rc = rc_ensure_pred(h))) return rc;
@@ -699,7 +701,11 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
   };
   const int64_t nblk = T * T;
   const size_t lds_pairs = (size_t)(2 * M * XST + 4 * 3 * M) * sizeof(double);
-  const size_t lds_mv = (size_t)(2 * M * XST + 4 * 2 * 128 + 3 * M * 128) * sizeof(double);
+  // canonical slices per k_sobol_matvec pass: as many column accumulators (1 KB each) as fit beside the two X panels in 160 KB of LDS
+  // -- all 3M for M <= 29, 18 at M = 64
+  const size_t lds_mv_fixed = (size_t)(2 * M * XST + 4 * 2 * 128) * sizeof(double);
+  const int mv_window = (int)std::min<size_t>((size_t)3 * M, (160 * 1024 - 512 - lds_mv_fixed) / (128 * sizeof(double)));
+  const size_t lds_mv = lds_mv_fixed + (size_t)mv_window * 128 * sizeof(double);
   RC_HIP(hipFuncSetAttribute((const void*)k_sobol_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
   RC_HIP(hipFuncSetAttribute((const void*)k_sobol_matvec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mv));
   const double pairs = (double)h->N * (double)h->N;
@@ -723,17 +729,54 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
     RC_HIP(hipStreamSynchronize(h->stream));
     return 0;
   };
-  auto matvec_pass = [&](const std::vector<double>& c, const double* gl, double* Uout) -> int {
-    int r = rc_ensure_partial(h, (size_t)T * 3 * M * Np);
+  // one arbitrary slice [ma, mb) of the same quadratic form (k_sobol_pairs mode 1)
+  auto pair_pass_one = [&](const std::vector<double>& c, const double* gl, const double* gj, int ma, int mb, double* value) -> int {
+    int r = rc_ensure_partial(h, (size_t)nblk * 3 * M);
     if (r) return r;
     RC_HIP(hipMemcpyAsync(consts_d, c.data(), (size_t)4 * M * sizeof(double), hipMemcpyHostToDevice, h->stream));
     {
-      RcProfScope ps(h, RC_K_SOBOL, pairs * (double)(3 * M - 1));
-      hipLaunchKernelGGL(k_sobol_matvec, dim3((unsigned)T, (unsigned)T), dim3(256), lds_mv, h->stream, h->X, gl, consts_d, M, Np, h->partial);
+      RcProfScope ps(h, RC_K_SOBOL, pairs);
+      hipLaunchKernelGGL(k_sobol_pairs<false>, dim3((unsigned)T, (unsigned)T), dim3(256), lds_pairs, h->stream, h->X, gl, gj, consts_d, M, 1, ma,
+                         mb, h->partial);
       RC_HIP(hipGetLastError());
     }
-    const int64_t n = (int64_t)3 * M * Np;
-    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->partial, T, n, Uout);
+    hipLaunchKernelGGL(k_rowreduce_s, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, 3 * M, sums_d + 8);
+    RC_HIP(hipGetLastError());
+    RC_HIP(hipMemcpyAsync(value, sums_d + 8, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RC_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+  };
+  // u_S for all canonical slices -> Uout[3M][Np], the window of column accumulators walked over the 3M slice indices
+  auto matvec_pass = [&](const std::vector<double>& c, const double* gl, double* Uout) -> int {
+    int r = rc_ensure_partial(h, (size_t)T * mv_window * Np);
+    if (r) return r;
+    RC_HIP(hipMemcpyAsync(consts_d, c.data(), (size_t)4 * M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int s_lo = 0; s_lo < 3 * M; s_lo += mv_window) {
+      const int s_hi = std::min(3 * M, s_lo + mv_window), nS = s_hi - s_lo;
+      {
+        RcProfScope ps(h, RC_K_SOBOL, pairs * (double)nS);
+        hipLaunchKernelGGL(k_sobol_matvec, dim3((unsigned)T, (unsigned)T), dim3(256), lds_mv, h->stream, h->X, gl, consts_d, M, Np, h->partial, 0, 0,
+                           M, s_lo, s_hi);
+        RC_HIP(hipGetLastError());
+      }
+      const int64_t n = (int64_t)nS * Np;
+      hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->partial, T, n, Uout + (size_t)s_lo * Np);
+      RC_HIP(hipGetLastError());
+    }
+    return 0;
+  };
+  // u_S for one arbitrary slice -> Uout[Np]
+  auto matvec_one = [&](const std::vector<double>& c, const double* gl, int ma, int mb, double* Uout) -> int {
+    int r = rc_ensure_partial(h, (size_t)T * Np);
+    if (r) return r;
+    RC_HIP(hipMemcpyAsync(consts_d, c.data(), (size_t)4 * M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    {
+      RcProfScope ps(h, RC_K_SOBOL, pairs);
+      hipLaunchKernelGGL(k_sobol_matvec, dim3((unsigned)T, (unsigned)T), dim3(256), lds_mv, h->stream, h->X, gl, consts_d, M, Np, h->partial, 1, ma,
+                         mb, 0, 1);
+      RC_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, h->stream, h->partial, T, Np, Uout);
     RC_HIP(hipGetLastError());
     return 0;
   };
@@ -771,8 +814,8 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
   }
   const int64_t rows = 6 * M + 1, rows_padded = ((rows + 127) / 128) * 128;
   if (mo) RC_HIP(hipMemsetAsync(h->KsT, 0, (size_t)rows_padded * h->Np * sizeof(double), h->stream));
-  hipLaunchKernelGGL(k_sobol_psi_rows, dim3((unsigned)((Np + 255) / 256), (unsigned)rows_padded), dim3(256), 0, h->stream, U, Ufull_bb, g0_b, M,
-                     Np, rows_padded, h->KsT, h->Np, mo ? (int64_t)out_b * h->Nb : 0);
+  hipLaunchKernelGGL(k_sobol_psi_rows, dim3((unsigned)((Np + 255) / 256), (unsigned)rows_padded), dim3(256), 0, h->stream, U, Ufull_bb, g0_b,
+                     3 * M, Np, rows_padded, h->KsT, h->Np, mo ? (int64_t)out_b * h->Nb : 0);
   RC_HIP(hipGetLastError());
   if ((rc = rc_launch_predict_var(h, rows_padded))) return rc;
   std::vector<double> pv(rows_padded);
@@ -782,6 +825,7 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
   for (int s = 0; s < n_slices; ++s) {
     const int a = slices[2 * s], b = slices[2 * s + 1];
     if (a == b) { phi_d_out[s] = psi_d_out[s] = phi_m_out[s] = psi_m_out[s] = 0.0; continue; }
+    if (!is_canonical(a, b)) continue;                              // below
     const int idx = (a == 0) ? M + (b - 1) : ((b == M) ? 2 * M + (a - 1) : a);
     phi_d_out[s] = pre_b * canonD[idx];
     phi_m_out[s] = pre_b * canonM[idx];
@@ -797,9 +841,45 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
     // case: k_sobol_psi_rows adds Ufull = Ufull_bb), and |psi_full_bb|^2 is row 6M.
     for (int s = 0; s < n_slices; ++s) {
       const int a = slices[2 * s], b = slices[2 * s + 1];
-      if (a == b) continue;
+      if (a == b || !is_canonical(a, b)) continue;
       const int idx = (a == 0) ? M + (b - 1) : ((b == M) ? 2 * M + (a - 1) : a);
       psi_m_out[s] = 0.5 * (pv[3 * M + idx] - pv[idx] - pv[6 * M]);
+    }
+  }
+  // ---- arbitrary slices (gsa/calibrators.py:348-373 takes any [m0, m1)): the same four ingredients, one slice at a time for the
+  // quadratic forms and the u vector, the psi norms of up to 3M of them per GEMM. The canonical U rows are no longer needed (their
+  // norms are on the host), only the (b,b) full-model vector, which moves to a scratch row of its own.
+  std::vector<int> generic;
+  for (int s = 0; s < n_slices; ++s)
+    if (!is_canonical(slices[2 * s], slices[2 * s + 1])) generic.push_back(s);
+  if (!generic.empty()) {
+    RC_HIP(hipMemcpyAsync(al_a, Ufull_bb, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));      // alpha_a is spent: g_a exists
+    const double* Ufull_keep = al_a;
+    const int chunk = 3 * M;
+    for (size_t g0i = 0; g0i < generic.size(); g0i += chunk) {
+      const int G = (int)std::min<size_t>(chunk, generic.size() - g0i);
+      for (int g = 0; g < G; ++g) {
+        const int s = generic[g0i + g], a = slices[2 * s], b = slices[2 * s + 1];
+        double qd = 0.0, qm = 0.0;
+        if ((rc = pair_pass_one(cD, g_a, g_a, a, b, &qd)) || (rc = pair_pass_one(cM, gt_b, g_a, a, b, &qm))) return rc;
+        phi_d_out[s] = pre_b * qd;
+        phi_m_out[s] = pre_b * qm;
+        if ((rc = matvec_one(cH, g_a, a, b, U + (size_t)g * Np))) return rc;
+      }
+      const int64_t rows_g = 2 * G + 1, rows_g_padded = ((rows_g + 127) / 128) * 128;
+      if (mo) RC_HIP(hipMemsetAsync(h->KsT, 0, (size_t)rows_g_padded * h->Np * sizeof(double), h->stream));
+      hipLaunchKernelGGL(k_sobol_psi_rows, dim3((unsigned)((Np + 255) / 256), (unsigned)rows_g_padded), dim3(256), 0, h->stream, U, Ufull_keep, g0_b,
+                         G, Np, rows_g_padded, h->KsT, h->Np, mo ? (int64_t)out_b * h->Nb : 0);
+      RC_HIP(hipGetLastError());
+      if ((rc = rc_launch_predict_var(h, rows_g_padded))) return rc;
+      std::vector<double> pg(rows_g_padded);
+      RC_HIP(hipMemcpyAsync(pg.data(), h->pvar, (size_t)rows_g_padded * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      RC_HIP(hipStreamSynchronize(h->stream));
+      for (int g = 0; g < G; ++g) {
+        const int s = generic[g0i + g];
+        psi_d_out[s] = pg[g];
+        psi_m_out[s] = 0.5 * (pg[G + g] - pg[g] - pg[2 * G]);       // polarisation against the (b,b) full-model vector
+      }
     }
   }
   return 0;

@@ -2,6 +2,7 @@
 // alpha = K^-1 y, the LML value, and the final reduction of the fused gradient partials.
 // Reference call sites: GPflow multivariate_normal / cholesky_solve at gpr/models.py:360-370, 441-444.
 #include "common.h"
+#include <string.h>
 
 int rc_ensure_partial(rcgp_handle_s* h, size_t elems) {
   if (h->partial_elems >= elems) return 0;
@@ -171,18 +172,20 @@ __global__ void __launch_bounds__(1024) k_lml_reduce(const double* __restrict__ 
   if (threadIdx.x == 0) { out[0] = sa[0]; out[1] = sb[0]; }
 }
 
+// The numbers of one evaluation leave the device in ONE copy into pinned host memory behind ONE synchronisation: the two LML sums,
+// the Cholesky status word and -- when the caller has queued them (rc_grad_queue / rc_grad_queue_mo) -- the reduced gradient sums.
 int rc_lml_value(rcgp_handle_s* h, double* lml) {
   {
     RcProfScope ps(h, RC_K_MISC, 0.0);
     hipLaunchKernelGGL(k_lml_reduce, dim3(1), dim3(1024), 0, h->stream, h->w, h->logdiag, h->Np, h->scal);
     RC_HIP(hipGetLastError());
   }
-  double host[2];
-  int info = 0;
-  RC_HIP(hipMemcpyAsync(host, h->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  RC_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  double* host = h->pin + h->pin_result;
+  RC_HIP(hipMemcpyAsync(host, h->scal, (RC_SCAL_INFO + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   RC_HIP(hipStreamSynchronize(h->stream));
   if (h->profiling) rc_prof_collect(h);      // the stream is idle here: harvesting the events costs no extra sync
+  int info = 0;
+  memcpy(&info, host + RC_SCAL_INFO, sizeof(int));
   if (info != 0) {
     h->err = "matrix is not positive definite: leading minor " + std::to_string(info);
     h->factored = false;
@@ -207,16 +210,18 @@ __global__ void __launch_bounds__(256) k_rowreduce(const double* __restrict__ pa
   if (threadIdx.x == 0) out[c] = sm[0];
 }
 
-int rc_grad_finish(rcgp_handle_s* h, int nrows, double* grad) {
+// Queue the final reduction of the gradient partials (-> scal[8 ...]); rc_lml_value then brings them down with the LML sums.
+int rc_grad_queue(rcgp_handle_s* h, int nrows) {
+  RcProfScope ps(h, RC_K_MISC, 0.0);
+  hipLaunchKernelGGL(k_rowreduce, dim3((unsigned)(h->M + 2)), dim3(256), 0, h->stream, h->partial, (int64_t)nrows, h->M + 2, h->scal + 8);
+  RC_HIP(hipGetLastError());
+  return 0;
+}
+
+// After rc_lml_value: the gradient from the sums in the pinned result block.
+int rc_grad_finish(rcgp_handle_s* h, double* grad) {
   const int M = h->M;
-  {
-    RcProfScope ps(h, RC_K_MISC, 0.0);
-    hipLaunchKernelGGL(k_rowreduce, dim3((unsigned)(M + 2)), dim3(256), 0, h->stream, h->partial, (int64_t)nrows, M + 2, h->scal + 8);
-    RC_HIP(hipGetLastError());
-  }
-  std::vector<double> host(M + 2);
-  RC_HIP(hipMemcpyAsync(host.data(), h->scal + 8, (size_t)(M + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  RC_HIP(hipStreamSynchronize(h->stream));
+  const double* host = h->pin + h->pin_result + 8;
   for (int m = 0; m < M; ++m) grad[m] = 0.5 * host[m] / h->ell[m];     // dK/dell_m = K (z_im - z_jm)^2 / ell_m
   grad[M] = 0.5 * host[M] / h->var;
   grad[M + 1] = 0.5 * host[M + 1];
@@ -246,27 +251,32 @@ __global__ void __launch_bounds__(256) k_reduce_pairs(const double* __restrict__
 }
 
 // Partial derivatives of the LML with every entry of ell (L x M), F (L x L) and Sigma (L x L) treated as independent
-// (k_grad_mo explains the per-tile sums and their weights).
-int rc_grad_finish_mo(rcgp_handle_s* h, double* g_ell, double* g_F, double* g_S) {
+// (k_grad_mo explains the per-tile sums and their weights). rc_grad_queue_mo queues the reduction over the tiles of every block pair
+// and its copy into the pinned result block; rc_grad_finish_mo runs on the host after rc_lml_value has synchronised.
+int rc_grad_queue_mo(rcgp_handle_s* h) {
   const int M = h->M, L = h->L, cols = 2 * M + 2, npairs = L * (L + 1) / 2;
   const int tb = (int)(h->Nb / 128);
   const int64_t T = h->Np / 128;
   double* out_d = h->partial + (size_t)(T * (T + 1) / 2) * cols;          // behind the per-tile rows
-  int rc = 0;
-  if (h->partial_elems < (size_t)(T * (T + 1) / 2) * cols + (size_t)npairs * cols) { h->err = "rc_grad_finish_mo: scratch too small"; return -7; }
+  if (h->partial_elems < (size_t)(T * (T + 1) / 2) * cols + (size_t)npairs * cols) { h->err = "rc_grad_queue_mo: scratch too small"; return -7; }
+  if (h->pin_elems < h->pin_result + RC_SCAL_ELEMS + (size_t)npairs * cols) { h->err = "rc_grad_queue_mo: staging buffer too small"; return -7; }
   {
     RcProfScope ps(h, RC_K_MISC, 0.0);
     hipLaunchKernelGGL(k_reduce_pairs, dim3((unsigned)cols, (unsigned)npairs), dim3(256), 0, h->stream, h->partial, tb, cols, out_d);
     RC_HIP(hipGetLastError());
   }
-  std::vector<double> host((size_t)npairs * cols);
-  RC_HIP(hipMemcpyAsync(host.data(), out_d, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  RC_HIP(hipStreamSynchronize(h->stream));
+  RC_HIP(hipMemcpyAsync(h->pin + h->pin_result + RC_SCAL_ELEMS, out_d, (size_t)npairs * cols * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return 0;
+}
+
+int rc_grad_finish_mo(rcgp_handle_s* h, double* g_ell, double* g_F, double* g_S) {
+  const int M = h->M, L = h->L, cols = 2 * M + 2;
+  const double* host = h->pin + h->pin_result + RC_SCAL_ELEMS;
   std::vector<double> R((size_t)L * M, 0.0);
   int p = 0;
   for (int bi = 0; bi < L; ++bi)
     for (int bj = 0; bj <= bi; ++bj, ++p) {
-      const double* o = host.data() + (size_t)p * cols;
+      const double* o = host + (size_t)p * cols;
       for (int m = 0; m < M; ++m) {
         R[(size_t)bi * M + m] += o[m];
         if (bi != bj) R[(size_t)bj * M + m] -= o[M + m];
@@ -277,5 +287,5 @@ int rc_grad_finish_mo(rcgp_handle_s* h, double* g_ell, double* g_F, double* g_S)
     }
   for (int l = 0; l < L; ++l)
     for (int m = 0; m < M; ++m) g_ell[l * M + m] = 0.5 * R[(size_t)l * M + m] / h->ell[(size_t)l * M + m];
-  return rc;
+  return 0;
 }

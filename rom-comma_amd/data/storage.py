@@ -75,14 +75,15 @@ class Repository:
         self._meta_json = self._folder / 'meta.json'
         self._csv = self._folder / 'data.csv'
         self._data = None
-        init_mode = kwargs.get('init_mode', Repository._InitMode.READ)
-        if init_mode <= Repository._InitMode.READ:
-            self._meta = self.read_meta()
-            if init_mode is Repository._InitMode.READ:
-                self._data = Frame(self._csv)
-        else:
-            shutil.rmtree(self._folder, ignore_errors=True)
-            self._folder.mkdir(mode=0o777, parents=True, exist_ok=False)
+        mode = Repository._InitMode(kwargs.get('init_mode', Repository._InitMode.READ))
+        if mode is Repository._InitMode.CREATE:              # a fresh, empty folder; the caller supplies meta and data next
+            if self._folder.exists():
+                shutil.rmtree(self._folder)
+            self._folder.mkdir(mode=0o777, parents=True)
+            return
+        self._meta = self.read_meta()                        # READ and READ_META_ONLY both need meta.json ...
+        if mode is Repository._InitMode.READ:
+            self._data = Frame(self._csv)                    # ... only READ loads data.csv
 
     # ---- plain accessors
     @property
@@ -197,12 +198,12 @@ class Repository:
         """One single-output Repository ``Y.l`` per output column (data/storage.py:226-243)."""
         if isinstance(self, Fold):
             raise TypeError('Cannot Y_split a Fold, only a Repository.')
+        M, frame = self.M, self.data.df
         for l in range(self.L):
-            destination = self.folder / f'Y.{l:d}'
-            data = self.data.df.take(list(range(self.M)) + [self.M + l], axis=1)
-            meta = deepcopy(self._meta)
-            meta['data']['L'] = 1
-            Repository.from_df(destination, data, meta)
+            one_output = pd.concat([frame.iloc[:, :M], frame.iloc[:, [M + l]]], axis=1)       # all inputs + output column l
+            split_meta = deepcopy(self._meta)
+            split_meta['data'] = {**split_meta['data'], 'L': 1}
+            Repository.from_df(self.folder / f'Y.{l:d}', one_output, split_meta)
 
     @property
     def Y_splits(self) -> List[Tuple[int, Path]]:

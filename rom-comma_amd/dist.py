@@ -105,3 +105,27 @@ def max_over_ranks(value: float) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+
+def agree_on_failure(error: BaseException | None) -> None:
+    """Called by every rank after its share of a sharded loop, with the exception it caught (or None). If ANY rank failed, every
+    rank raises -- the failing ones their own exception, the others a RuntimeError naming the ranks -- so that nobody is left
+    waiting in the next collective for a rank that has gone (the reference's loop is sequential and simply propagates,
+    user/run.py:60-61). One all-reduce (MAX) of a flag per rank."""
+    if not is_distributed():
+        if error is not None:
+            raise error
+        return
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    flags = torch.zeros(world, dtype=torch.int32, device=_device())
+    if error is not None:
+        flags[rank] = 1
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    failed = [r for r in range(world) if int(flags[r].item())]
+    if error is not None:
+        raise error
+    if failed:
+        raise RuntimeError(f'rank(s) {failed} failed in a sharded loop; rank {rank} stops with them')

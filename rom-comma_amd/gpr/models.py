@@ -68,24 +68,37 @@ class GPR(Model):
 
     def __init__(self, name: str, fold: Fold, is_read: bool | None, is_covariant: bool, is_isotropic: bool,
                  kernel_parameters: Kernel.Data | None = None, likelihood_variance: np.ndarray | None = None):
-        """Pulls X (N,M) and Y (N,L) from ``fold`` as float64 copies, builds the Likelihood and Kernel stores under
-        ``fold.folder / name`` and broadcasts them to (1,L) variances and (L,M) or (L,1) lengthscales (gpr/models.py:290-320)."""
+        """A GP called ``name`` inside ``fold``. Contract (reference gpr/models.py:290-320):
+
+        * the training arrays are float64 COPIES of the fold's X (N,M) and Y (N,L) -- later edits of the fold do not reach the GP;
+        * the model store is ``fold.folder / name``; ``is_read`` decides between reading it and starting from defaults;
+        * an explicit ``likelihood_variance`` / ``kernel_parameters`` wins over what is on file; a kernel that is read back is
+          re-created from the type identifier in ``kernel.csv``, a new one records its identifier there;
+        * finally everything is broadcast to L outputs (and M or 1 lengthscales), which also builds the implementation.
+        """
         self._fold = fold
-        self._X = self._fold.X.to_numpy(dtype=np.float64, copy=True)
-        self._Y = self._fold.Y.to_numpy(dtype=np.float64, copy=True)
-        self._N, self._M, self._L = self._fold.N, self._fold.M, self._fold.L
-        super().__init__(self._fold.folder / name, is_read)
-        self._likelihood = Likelihood(self, is_read) if likelihood_variance is None else Likelihood(self, is_read, variance=likelihood_variance)
-        if is_read and kernel_parameters is None:
-            KernelType = Kernel.TypeFromIdentifier(self.data.frames.kernel.np[0, 0])
-            self._kernel = KernelType(self._folder / self.KERNEL_FOLDER_NAME, is_read)
-        else:
-            if kernel_parameters is None:
-                kernel_parameters = Kernel.Data(self._folder / self.KERNEL_FOLDER_NAME)
-            KernelType = Kernel.TypeFromParameters(kernel_parameters)
-            self._kernel = KernelType(self._folder / self.KERNEL_FOLDER_NAME, is_read, **kernel_parameters.asdict())
-            self._data.replace(kernel=np.atleast_2d(KernelType.TYPE_IDENTIFIER))
+        self._N, self._M, self._L = fold.N, fold.M, fold.L
+        self._X, self._Y = (np.array(frame.to_numpy(), dtype=np.float64, order='C', copy=True) for frame in (fold.X, fold.Y))
+        super().__init__(fold.folder / name, is_read)
+        noise_override = {} if likelihood_variance is None else {'variance': likelihood_variance}
+        self._likelihood = Likelihood(self, is_read, **noise_override)
+        self._kernel = self._restored_kernel() if (is_read and kernel_parameters is None) else self._fresh_kernel(is_read, kernel_parameters)
         self.broadcast_parameters(is_covariant, is_isotropic)
+
+    def _restored_kernel(self) -> Kernel:
+        """The kernel whose type ``kernel.csv`` names, read from the kernel folder."""
+        identifier = self.data.frames.kernel.np[0, 0]
+        return Kernel.TypeFromIdentifier(identifier)(self._folder / self.KERNEL_FOLDER_NAME, True)
+
+    def _fresh_kernel(self, is_read: bool | None, parameters: Kernel.Data | None) -> Kernel:
+        """A kernel of the type ``parameters`` belong to (default parameters when none are given); its identifier goes to ``kernel.csv``."""
+        kernel_folder = self._folder / self.KERNEL_FOLDER_NAME
+        if parameters is None:
+            parameters = Kernel.Data(kernel_folder)
+        kernel_type = Kernel.TypeFromParameters(parameters)
+        kernel = kernel_type(kernel_folder, is_read, **parameters.asdict())
+        self._data.replace(kernel=np.atleast_2d(kernel_type.TYPE_IDENTIFIER))
+        return kernel
 
     # ---- plain accessors
     @classmethod
@@ -166,18 +179,21 @@ class GPR(Model):
 
     # ---- inherited helpers (pure host code)
     def predict_df(self, x: np.ndarray, y_instead_of_f: bool = True, is_normalized: bool = True) -> pd.DataFrame:
-        """Prediction as a frame with columns (X, Mean, SD), optionally un-normalised (gpr/models.py:202-222)."""
-        Y_heading = self._fold.meta['data']['Y_heading']
+        """The prediction at ``x`` (o,M) as one frame: the M input columns under the fold's X heading, then L columns 'Mean' and L
+        columns 'SD', second-level labels as in the fold's test data. ``is_normalized=False`` maps the inputs and the mean back to
+        the original units and rescales (not shifts) the SD (contract: SURVEY.md section 8f rank 3; reference gpr/models.py:202-222)."""
+        labels = self._fold.test_data.df.columns                      # (X heading, X.m) ... (Y heading, Y.l)
+        y_heading = self._fold.meta['data']['Y_heading']
+        y_labels = labels[self._M:]
+        x = np.asarray(x, dtype=np.float64)
         mean, sd = self.predict(x, y_instead_of_f)
-        result = pd.DataFrame(np.concatenate([x, mean], axis=1), columns=self._fold.test_data.df.columns)
-        predictive_std = result.loc[:, [Y_heading]].copy()
-        predictive_std.iloc[:] = sd
+        located = pd.DataFrame(np.hstack([x, mean]), columns=labels)
+        spread = pd.DataFrame(np.asarray(sd, dtype=np.float64), columns=y_labels)
         if not is_normalized:
-            result = self._fold.normalization.undo_from(result)
-            predictive_std = self._fold.normalization.unscale_Y(predictive_std)
-        result = result.rename(columns={Y_heading: 'Mean'}, level=0)
-        predictive_std = predictive_std.rename(columns={Y_heading: 'SD'}, level=0)
-        return result.join([predictive_std])
+            normalization = self._fold.normalization
+            located, spread = normalization.undo_from(located), normalization.unscale_Y(spread)
+        relabel = lambda frame, new: frame.rename(columns={y_heading: new}, level=0)      # noqa: E731
+        return pd.concat([relabel(located, 'Mean'), relabel(spread, 'SD')], axis=1)
 
     def test(self) -> DataFrameCSV:
         """Score the GP on the fold's held-out rows: per row Mean, SD, Abs Error, Z Score, Outlier (Z^2 > 4, plus Any/All
@@ -206,13 +222,19 @@ class GPR(Model):
         return frame
 
     def broadcast_parameters(self, is_covariant: bool, is_isotropic: bool) -> 'GPR':
-        """Noise variance to (1,L) [or (L,L)], kernel variance likewise, lengthscales to (L,M) or (L,1) (gpr/models.py:274-288)."""
-        target_shape = (self._L, self._L) if is_covariant else (1, self._L)
-        self._likelihood.data.frames.variance.broadcast_value(target_shape=target_shape, is_diagonal=True)
-        self._kernel.broadcast_parameters(variance_shape=target_shape, M=1 if is_isotropic else self._M)
-        self._implementation = None
-        self._implementation = self.implementation
+        """Grow the stored parameters to this GP's shape and rebuild the implementation; returns ``self``. Variances (noise and
+        kernel) become (1,L), or (L,L) with only the diagonal kept for a covariant GP; lengthscales (L,M), or (L,1) when isotropic.
+        Growing is silent, an impossible broadcast raises IndexError in the frame (contract: reference gpr/models.py:274-288)."""
+        L, n_lengthscales = self._L, (1 if is_isotropic else self._M)
+        variance_shape = (L, L) if is_covariant else (1, L)
+        self._likelihood.data.frames.variance.broadcast_value(target_shape=variance_shape, is_diagonal=True)
+        self._kernel.broadcast_parameters(variance_shape=variance_shape, M=n_lengthscales)
+        self._reset_implementation()
         return self
+
+    def _reset_implementation(self) -> None:
+        self._implementation = None            # the property rebuilds on None
+        self._implementation = self.implementation
 
 
 class HipGP(GPR):
@@ -239,7 +261,12 @@ class HipGP(GPR):
         self._handle = None
         self._cache: Dict[int, Dict[str, np.ndarray]] = {}
         self._is_isotropic = bool(is_isotropic)
+        self._live_noise = None            # covariant GP: the full fitted likelihood covariance, from calibrate() until the next rebuild
         super().__init__(name, fold, is_read, is_covariant, is_isotropic, kernel_parameters, likelihood_variance)
+
+    def broadcast_parameters(self, is_covariant: bool, is_isotropic: bool) -> 'GPR':
+        self._live_noise = None            # a rebuilt model starts from the stored, diagonalised likelihood variance
+        return super().broadcast_parameters(is_covariant, is_isotropic)
 
     # ---- device plumbing
     @property
@@ -272,10 +299,15 @@ class HipGP(GPR):
 
     def _hyper_mo(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """(lengthscales (L,M), kernel variance (L,L), likelihood variance (L,L)) of the covariant GP as MOGPR.__init__ receives
-        them (gpr/models.py:335-338). The reference then reduces ANY likelihood variance to its diagonal: the shape test at
-        gpf/models.py:121 compares a bound method with a tuple, is always true, and band_part(., 0, 0) follows (:122-123)."""
+        them (gpr/models.py:335-338). On CONSTRUCTION the reference reduces any likelihood variance to its diagonal: the shape test
+        at gpf/models.py:121 compares a bound method with a tuple, is always true, and band_part(., 0, 0) follows (:122-123). But
+        the object it goes on using after ``calibrate`` is the trained MOGPR itself (``self._implementation[0]``, :359-367), whose
+        likelihood covariance was trained in full (``'covariance': True``): until the model is rebuilt (broadcast_parameters, i.e.
+        construction or a re-read), test / predict / K_inv_Y / Sobol see the full fitted Sigma -- kept here in ``_live_noise``."""
         record = self._kernel.implementation[0]
         lengthscales = np.broadcast_to(np.asarray(record['lengthscales'], dtype=np.float64), (self._L, self._M)).copy()
+        if self._live_noise is not None:
+            return lengthscales, np.asarray(record['variance'], dtype=np.float64), self._live_noise
         noise = np.broadcast_to(np.asarray(self._likelihood.data.frames.variance.np, dtype=np.float64), (self._L, self._L))
         return lengthscales, np.asarray(record['variance'], dtype=np.float64), np.diag(np.diag(noise))
 
@@ -346,8 +378,8 @@ class HipGP(GPR):
             n_ell = 1 if self._is_isotropic else self._M
             self._kernel.data.replace(variance=fit['variance'], lengthscales=fit['lengthscales'][:, :n_ell])
             self._kernel._implementation = None
-            self._implementation = None
-            self._implementation = self.implementation
+            self._reset_implementation()
+            self._live_noise = np.array(fit['noise'], dtype=np.float64)        # the live model keeps its full Sigma (see _hyper_mo)
             return meta
         fits = []
         for l in range(self._L):
@@ -368,8 +400,7 @@ class HipGP(GPR):
         self._kernel.data.replace(variance=np.array([[fit['variance'] for fit in fits]]),
                                   lengthscales=np.stack([fit['lengthscales'][:n_ell] for fit in fits]))
         self._kernel._implementation = None
-        self._implementation = None
-        self._implementation = self.implementation
+        self._reset_implementation()
         return meta
 
     def log_marginal_likelihood(self) -> np.ndarray:

@@ -13,6 +13,7 @@ import numpy as np
 
 from romcomma_amd import _lib
 from romcomma_amd.gpr.models import GPR
+from romcomma_amd.gpr.sharded import OutputShard, sobol_rows
 from romcomma_amd.gsa.base import Calibrator
 
 
@@ -67,11 +68,21 @@ class ClosedSobol(Calibrator):
     def META(cls) -> Dict[str, Any]:
         return {}
 
-    def __init__(self, gp: GPR, **kwargs: Any):
+    def __init__(self, gp: GPR | OutputShard, **kwargs: Any):
         self.gp = gp
         self.meta = self.META | kwargs
         self.L, self.M, self.N = gp.L, gp.M, gp.N
         self.is_F_diagonal = self.meta.pop('is_F_diagonal', None)
+        self.is_sharded = isinstance(gp, OutputShard)
+        self._cache: Dict[Tuple[int, int], np.ndarray] = {}
+        if self.is_sharded:
+            # independent outputs living on different ranks: the shard has already gathered (F, Lambda, K_inv_Y) of all of them
+            self.is_F_diagonal, self.is_gp_covariant = True, False
+            self.F, self.Lambda, self.K_inv_Y = gp.F, gp.Lambda, gp.K_inv_Y
+            self.owned = list(gp.owned_outputs)
+            self._calibrate()
+            return
+        self.owned = list(range(self.L))
         if self.is_F_diagonal is None:
             gp_options = gp.read_meta() if gp._meta_json.exists() else gp.META
             self.is_F_diagonal = not gp_options.get('kernel', {}).get('covariance', False)      # gsa/calibrators.py:129-132
@@ -85,7 +96,6 @@ class ClosedSobol(Calibrator):
             self.F = F.reshape(self.L, self.L)
         self.Lambda = np.broadcast_to(np.asarray(gp.kernel.data.frames.lengthscales.np, dtype=np.float64), (self.L, self.M)).copy()
         self.K_inv_Y = np.asarray(gp.K_inv_Y, dtype=np.float64).reshape(self.L, self.N)          # also leaves each alpha cached on host
-        self._cache: Dict[Tuple[int, int], np.ndarray] = {}
         self._calibrate()
 
     # ---- device calls
@@ -98,6 +108,10 @@ class ClosedSobol(Calibrator):
             block = covariant_V(self.gp._select_mo(), self.K_inv_Y, self.F, self.Lambda, missing, self.is_F_diagonal)
             for i, s in enumerate(missing):
                 self._cache[s] = block[i]
+        elif missing and self.is_sharded:
+            block = sobol_rows(self.gp, missing)            # row l from the rank that owns output l (one all-gather)
+            for i, s in enumerate(missing):
+                self._cache[s] = block[..., i]
         elif missing:
             block = np.empty((self.L, self.L, len(missing)))
             for l in range(self.L):
@@ -162,7 +176,7 @@ class ClosedSobolWithError(ClosedSobol):
         L = self.L
         D = np.zeros((L, L, len(slices)))
         Mx = np.zeros((L, L, len(slices)))
-        for b in range(L):
+        for b in self.owned:                                           # column b needs the Cholesky factor of output b: its owner's job
             handle = self.gp._select_mo() if self.is_gp_covariant else self.gp._select(b)
             for a in range(L):
                 if self.is_gp_covariant:         # both outputs live in the one (LN) system; psi_factor embeds in block b (:304-308)
@@ -174,6 +188,9 @@ class ClosedSobolWithError(ClosedSobol):
                 doubled = 2.0 if a == b else 1.0                       # set_diag(2 * diag): gsa/calibrators.py:281,284,322
                 D[a, b] = doubled * (phi_d - psi_d)
                 Mx[a, b] = doubled * (phi_m - psi_m)
+        if self.is_sharded:                                            # columns from their owners
+            both = self.gp.gather_output_rows(np.ascontiguousarray(np.stack([D, Mx], axis=2).transpose(1, 0, 2, 3)))   # [b][a][D|Mx][slice]
+            D, Mx = both[:, :, 0, :].transpose(1, 0, 2), both[:, :, 1, :].transpose(1, 0, 2)
         for i, s in enumerate(slices):
             self._W_diag[s] = D[..., i] + D[..., i].T                  # _W: W += transpose(W)  (:324-331)
             self._W_mixed[s] = Mx[..., i] + Mx[..., i].T

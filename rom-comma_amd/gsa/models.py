@@ -125,8 +125,11 @@ class Sobol(GSA):
         if self.is_error_calculated:
             return ClosedSobolWithError(self.gp, **meta)
         # The three kinds of one gp share every conditional variance: reuse the calibrator while the hyper-parameters stand.
-        signature = tuple(np.concatenate([np.ravel(self.gp.kernel.data.frames.lengthscales.np), np.ravel(self.gp.kernel.data.frames.variance.np),
-                                          np.ravel(self.gp.likelihood.data.frames.variance.np)]))
+        if hasattr(self.gp, 'hyper_signature'):            # an OutputShard (outputs on different ranks)
+            signature = self.gp.hyper_signature()
+        else:
+            signature = tuple(np.concatenate([np.ravel(self.gp.kernel.data.frames.lengthscales.np), np.ravel(self.gp.kernel.data.frames.variance.np),
+                                              np.ravel(self.gp.likelihood.data.frames.variance.np)]))
         cached = getattr(self.gp, '_closed_sobol', None)
         if cached is None or cached[0] != signature:
             cached = (signature, ClosedSobol(self.gp, **meta))

@@ -66,3 +66,75 @@ def test_single_process_fallbacks():
     table = dist.all_gather_rows(np.array([[1.0, 2.0]]), 1, [0])
     assert table.tolist() == [[1.0, 2.0]]
     assert dist.max_over_ranks(2.5) == 2.5
+
+
+class _StubFrames:
+    def __init__(self, value):
+        self.np = np.atleast_2d(np.asarray(value, dtype=float))
+
+
+class _StubGP:
+    """The few attributes gpr.sharded.OutputShard reads from a single-output HipGP."""
+
+    def __init__(self, l, N, M):
+        rng = np.random.default_rng(100 + l)
+        self.N, self.M, self.L, self._is_covariant = N, M, 1, False
+        self.K_inv_Y = rng.normal(size=(1, 1, N))
+        kernel_frames = type('F', (), {'lengthscales': _StubFrames(rng.uniform(0.5, 2.0, (1, M))), 'variance': _StubFrames([[1.0 + l]])})()
+        self.kernel = type('K', (), {'data': type('D', (), {'frames': kernel_frames})()})()
+        self.closed = False
+
+    def close(self):
+        self.closed = True
+
+
+def _shard_worker(rank: int, world: int, port: int, tmp: str):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    from romcomma_amd import dist
+    from romcomma_amd.gpr.sharded import OutputShard
+    dist.init_process_group('gloo')
+    L, N, M = 5, 37, 3                                     # five outputs on two ranks: 3 + 2
+    owned = dist.shard_units(L, rank, world)
+    gps = {l: _StubGP(l, N, M) for l in owned}
+    shard = OutputShard(gps, L, Path(tmp) / 'merged' / 'gpr.v.a')
+    assert shard.owned_outputs == owned and (shard.N, shard.M, shard.L) == (N, M, L)
+    assert shard.is_writer == (rank == 0) and (shard.folder == Path(tmp) / 'merged' / 'gpr.v.a') == (rank == 0)
+    for l in range(L):                                     # every rank holds every output's (alpha, lengthscales, variance)
+        ref = _StubGP(l, N, M)
+        assert np.array_equal(shard.K_inv_Y[l], ref.K_inv_Y.reshape(N)) and np.array_equal(shard.Lambda[l], ref.kernel.data.frames.lengthscales.np[0])
+        assert shard.F[l] == 1.0 + l
+    block = np.zeros((L, L, 4))
+    for l in owned:
+        block[l] = 10.0 * l + np.arange(L)[:, None] + 0.1 * np.arange(4)[None, :]
+    full = shard.gather_output_rows(block)
+    for l in range(L):
+        assert np.array_equal(full[l], 10.0 * l + np.arange(L)[:, None] + 0.1 * np.arange(4)[None, :])
+    shard.close()
+    assert all(gp.closed for gp in gps.values())
+    # a failure on one rank reaches all of them instead of leaving the others in the next collective
+    try:
+        dist.agree_on_failure(ValueError('boom') if rank == 1 else None)
+        raised = None
+    except ValueError as exc:
+        raised = ('own', str(exc))
+    except RuntimeError as exc:
+        raised = ('other', str(exc))
+    assert raised is not None and raised[0] == ('own' if rank == 1 else 'other') and ('boom' in raised[1] or '[1]' in raised[1]), raised
+    dist.agree_on_failure(None)                            # nobody failed: nothing happens
+    np.save(Path(tmp) / f'shard{rank}.npy', full)
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+def test_output_shard_exchange_and_failure_agreement_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_shard_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / 'shard0.npy'), np.load(tmp_path / 'shard1.npy'))
+
+
+def test_failure_agreement_without_a_process_group():
+    from romcomma_amd import dist
+    dist.agree_on_failure(None)
+    with pytest.raises(KeyError):
+        dist.agree_on_failure(KeyError('x'))

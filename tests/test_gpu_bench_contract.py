@@ -32,4 +32,24 @@ def test_bench_json_contract(gpu):
     ch = d['stages']['cholesky']
     assert ch['ms'] > 0 and ch['frac'] == pytest.approx(ch['achieved_TFLOPs'] / r['peak'], rel=1e-12)
     c = d['cpu_baseline']
-    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == d['unit'] and c['sample']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == d['unit'] and c['sample'] and c['blas']
+    assert c['configs']['bench']['evaluation_s'] > 0 and c['configs']['bench']['N'] == 1024        # timed AT the configuration, not extrapolated
+    assert d['roofline']['stages']['cholesky']['frac'] == ch['frac'] and d['roofline']['stages']['gram']['bound'] == 'hbm'
+    assert d['config']['lbfgs_evaluations_timed_steps'] >= 2 * 5
+
+
+def test_bench_under_torch_distributed_run_exercises_rccl(gpu):
+    """The driver launches N > 1 as `python -m torch.distributed.run ... bench.py`; on the one-GPU box the same launcher with one rank and
+    --force-dist initialises the RCCL process group and runs the real collectives (barrier, all-reduce MAX, all_gather_into_tensor)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           str(ROOT / 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '1', '--rows', '1024', '--dims', '3', '--force-dist', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['value'] > 0 and 'cpu_baseline' not in d

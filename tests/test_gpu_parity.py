@@ -316,7 +316,7 @@ def test_sobol_error_terms(gpu, L):
     alpha = np.stack([o.k_inv_y(X, Y[:, l], ell[l], F[l], noise[l]) for l in range(L)])
     Kc = np.stack([o.k_cho(X, ell[l], F[l], noise[l]) for l in range(L)])
     ref = e.ClosedSobolWithErrorOracle(X, alpha[:, None, :], F[None, :], ell, Kc, is_T_partial=False)
-    slices = o.all_slices(M)[:-1] + [(M, M)]
+    slices = o.all_slices(M)[:-1] + [(M, M), (1, 3)]               # (1, 3): neither first-order, closed nor a complement
     for b in range(L):
         gp = gpu.RcGP(X, Y[:, b])
         gp.set_hyper(ell[b], F[b], noise[b])
@@ -326,8 +326,8 @@ def test_sobol_error_terms(gpu, L):
                 want = (0.0, 0.0, 0.0, 0.0) if sl[0] == sl[1] else e.error_terms_pair(X, a, b, ref.g0, ref.g, ref.phi, ref.ups, ref.pre, Kc, sl)
                 for k in range(4):
                     assert got[k][s] == pytest.approx(want[k], rel=1e-7, abs=1e-12), (a, b, sl, k)
-        with pytest.raises(gpu.RcgpError, match='only first-order'):
-            gp.sobol_error_terms([(1, 3)])
+        with pytest.raises(gpu.RcgpError, match='bad slice'):
+            gp.sobol_error_terms([(3, 1)])
         gp.close()
 
 
@@ -385,7 +385,7 @@ def test_sobol_error_terms_many_dimensions(gpu):
     alpha = o.k_inv_y(X, y, ell, F, noise)
     Kc = o.k_cho(X, ell, F, noise)[None]
     ref = e.ClosedSobolWithErrorOracle(X, alpha[None, None, :], np.array([[F]]), ell[None, :], Kc, is_T_partial=False)
-    slices = [(0, 1), (7, 8), (0, 5), (0, M), (12, M), (M - 1, M)]
+    slices = [(0, 1), (7, 8), (0, 5), (0, M), (12, M), (M - 1, M), (3, 11), (5, 7)]      # the last two: arbitrary slices
     gp = gpu.RcGP(X, y)
     gp.set_hyper(ell, F, noise)
     got = gp.sobol_error_terms(slices)
@@ -394,11 +394,22 @@ def test_sobol_error_terms_many_dimensions(gpu):
         for k in range(4):
             assert got[k][s] == pytest.approx(want[k], rel=1e-6, abs=1e-12 * abs(want[0]) + 1e-15), (sl, k)
     gp.close()
-    X30, y30 = o.synthetic_fold(64, 30)
-    gp = gpu.RcGP(X30, y30)
-    gp.set_hyper(np.full(30, 3.0), 1.0, 0.05)
-    with pytest.raises(gpu.RcgpError, match='at most 29'):
-        gp.sobol_error_terms([(0, 1)])
+    # M > 29: the column accumulators of the matvec kernel no longer fit in LDS together and the canonical slices take several passes
+    # (window of 3M indices walked by the host); same ingredients, same oracle, at a ragged N
+    N2, M2 = 139, 33
+    X2, y2 = o.synthetic_fold(N2, M2, k=2)
+    ell2 = np.random.default_rng(5).uniform(3.0, 9.0, M2)
+    alpha2 = o.k_inv_y(X2, y2, ell2, 0.9, 0.04)
+    Kc2 = o.k_cho(X2, ell2, 0.9, 0.04)[None]
+    ref2 = e.ClosedSobolWithErrorOracle(X2, alpha2[None, None, :], np.array([[0.9]]), ell2[None, :], Kc2, is_T_partial=False)
+    slices2 = [(0, 1), (32, 33), (0, 17), (0, M2), (20, M2), (1, M2), (4, 30)]
+    gp = gpu.RcGP(X2, y2)
+    gp.set_hyper(ell2, 0.9, 0.04)
+    got2 = gp.sobol_error_terms(slices2)
+    for s, sl in enumerate(slices2):
+        want = e.error_terms_pair(X2, 0, 0, ref2.g0, ref2.g, ref2.phi, ref2.ups, ref2.pre, Kc2, sl)
+        for k in range(4):
+            assert got2[k][s] == pytest.approx(want[k], rel=1e-6, abs=1e-12 * abs(want[0]) + 1e-15), (sl, k)
     gp.close()
 
 
@@ -476,3 +487,67 @@ def test_random_shapes_against_oracle(gpu):
         assert np.allclose(a, alpha, rtol=1e-6, atol=1e-8 * np.abs(alpha).max()), (N, M)
         assert np.allclose(m, mean, rtol=1e-8, atol=1e-9) and np.allclose(s, sd, rtol=1e-7, atol=1e-9), (N, M)
         assert np.allclose(V, Vref, rtol=1e-8, atol=1e-10 * np.abs(Vref).max()), (N, M)      # (the empty slice is 0 up to rounding)
+
+
+def test_stage_potrf_needs_a_fresh_gram_matrix(gpu):
+    """rcgp_stage_potrf factors what rcgp_stage_gram left in A; called twice (or after any factorising call) it would factor L as
+    if it were K and every later result on the handle would be garbage: refused with status -5."""
+    X, y = o.synthetic_fold(300, 3)
+    gp = gpu.RcGP(X, y)
+    with pytest.raises(gpu.RcgpError, match='hyper-parameters not set'):
+        gp.stage_potrf()
+    gp.set_hyper(*o.bench_hyper(3))
+    with pytest.raises(gpu.RcgpError, match='no fresh Gram'):
+        gp.stage_potrf()
+    gp.stage_gram()
+    gp.stage_potrf()
+    with pytest.raises(gpu.RcgpError, match='no fresh Gram'):
+        gp.stage_potrf()
+    ref = o.lml(X, y, *o.bench_hyper(3))
+    assert gp.lml() == pytest.approx(ref, rel=1e-10)            # the handle is still good
+    gp.lml_grad()
+    with pytest.raises(gpu.RcgpError, match='no fresh Gram'):   # A holds L again
+        gp.stage_potrf()
+    gp.close()
+
+
+@pytest.mark.parametrize('flags', [dict(train_lengthscales=False), dict(train_variance=False), dict(train_noise=False),
+                                   dict(train_lengthscales=False, train_noise=False), dict(train_variance=False, train_noise=False, is_isotropic=True)])
+def test_fit_with_parameters_held_fixed(gpu, flags):
+    """Kernel.calibrate / Likelihood.calibrate switch hyper-parameters off (gf.set_trainable, gpr/kernels.py:59-70,
+    gpr/models.py:71-80): the SciPy driver then runs over the remaining ones. Same driver, same start, same mask on the oracle and
+    on the GPU: same optimum (LML* within 1e-5 relative), the held parameters untouched, bit for bit."""
+    import scipy.optimize
+    from romcomma_amd.gpr.optimize import fit_lbfgsb, inv_softplus, softplus, sigmoid, LIKELIHOOD_LOWER
+    N, M = 400, 3
+    X, y = o.synthetic_fold(N, M, k=4)
+    iso = flags.get('is_isotropic', False)
+    ell0, var0, noise0 = (np.array([1.7]) if iso else np.array([1.5, 2.5, 4.0])), 1.3, 0.05
+    gp = gpu.RcGP(X, y)
+    fit = fit_lbfgsb(gp, ell0, var0, noise0, **flags)
+    gp.close()
+    tl, tv, tn = flags.get('train_lengthscales', True), flags.get('train_variance', True), flags.get('train_noise', True)
+    n_ell = ell0.shape[0]
+    u_all = np.concatenate([inv_softplus(ell0), [inv_softplus(var0)], [inv_softplus(noise0 - LIKELIHOOD_LOWER)]])
+    mask = np.array([tl] * n_ell + [tv, tn])
+
+    def objective(u_train):                                       # the oracle under the same parametrisation and mask
+        u = u_all.copy()
+        u[mask] = u_train
+        ell = np.broadcast_to(softplus(u[:n_ell]), (M,))
+        lml, g = o.lml_and_grad(X, y, ell, float(softplus(u[n_ell])), float(LIKELIHOOD_LOWER + softplus(u[n_ell + 1])))
+        g_ell = np.array([np.sum(g[:M])]) if iso else g[:M]
+        return -lml, -(np.concatenate([g_ell, g[M:]]) * sigmoid(u))[mask]
+    ref = scipy.optimize.minimize(objective, u_all[mask], jac=True, method='L-BFGS-B', options={'maxiter': 5000, 'gtol': 1e-16})
+    assert fit['log_marginal'] == pytest.approx(-ref.fun, rel=1e-5)
+    if not tl:
+        np.testing.assert_array_equal(fit['lengthscales'], np.broadcast_to(softplus(inv_softplus(ell0)), (M,)))
+    if not tv:
+        assert fit['variance'] == float(softplus(inv_softplus(var0)))
+    if not tn:
+        assert fit['noise'] == float(LIKELIHOOD_LOWER + softplus(inv_softplus(noise0 - LIKELIHOOD_LOWER)))
+    if iso:
+        assert np.all(fit['lengthscales'] == fit['lengthscales'][0])
+    u_ref = u_all.copy()
+    u_ref[mask] = ref.x
+    np.testing.assert_allclose(fit['lengthscales'], np.broadcast_to(softplus(u_ref[:n_ell]), (M,)), rtol=5e-3)

@@ -236,3 +236,20 @@ def test_predict_gradient_oracle_is_the_gradient_of_predict():
         fd = (o.predict(X, y, ell, var, noise, xp, False)[0] - o.predict(X, y, ell, var, noise, xm, False)[0]) / (2 * h)
         np.testing.assert_allclose(mean[:, m], fd, rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(cov, np.transpose(cov, (1, 0, 3, 2)), rtol=1e-10, atol=1e-14)     # symmetric under (O,M) <-> (o,m)
+
+
+def test_blas_arrangement_of_the_gradient_matches_the_plain_one():
+    """oracle.lml_and_grad_blas (what bench.py times as the CPU baseline: potrf + potri + BLAS-3 gradient sums) is the same function
+    as oracle.lml_and_grad (the plain restatement the GPU tests check against), ARD and isotropic."""
+    for N, M in ((97, 1), (300, 4), (257, 7)):
+        X, y = o.synthetic_fold(N, M, k=3)
+        ell = np.random.default_rng(N).uniform(0.5, 3.0, M)
+        for e in (ell, np.array([1.7])):
+            a, ga = o.lml_and_grad(X, y, e, 1.3, 0.02)
+            b, gb = o.lml_and_grad_blas(X, y, e, 1.3, 0.02)
+            assert b == pytest.approx(a, rel=1e-12)
+            np.testing.assert_allclose(gb, ga, rtol=1e-9, atol=1e-10 * np.max(np.abs(ga)))
+    X, y = o.synthetic_fold(200, 3)
+    V_all = o.sobol_V_pair(X, y, y, np.full(3, 0.3), np.full(3, 0.4), [(0, 3), (1, 2)])
+    V_stripes = sum(o.sobol_V_pair(X, y, y, np.full(3, 0.3), np.full(3, 0.4), [(0, 3), (1, 2)], rows=(r, min(r + 64, 200))) for r in range(0, 200, 64))
+    np.testing.assert_allclose(V_stripes, V_all, rtol=1e-12)
