@@ -166,10 +166,18 @@ def test_predict_gradient():
     kxx = F[:, None, :, None] * np.exp(-0.5 * np.einsum('...M,...M->...', d, d))
     ref[..., idx, idx] -= np.einsum('LM,lM,LOlo->OLolM', 1.0 / ell, 1.0 / ell, kxx)       # leave -V^T V
     assert np.allclose(got, ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+    # L n M > 4096 (one pass of derivative rows): 4200 rows go through in two chunks; points straddling the chunk boundary come out
+    # exactly as when they are asked for on their own (row r = (l n + o) M + m: a sub-set of points keeps its own (l, o, m) order)
+    big = np.random.default_rng(22).standard_normal((700, 3))
     with _lib.RcMOGP(X, Y) as gp:
         gp.set_hyper(ell, F, S)
-        with pytest.raises(_lib.RcgpError):
-            gp.predict_gradient(np.zeros((700, 3)))                       # L n M > 4096
+        m_big, c_big = gp.predict_gradient(big)                           # (L, n, M), (Lb, L, n, M, L, n, M)
+        pts = np.arange(660, 673)                                         # output 1's rows 4080..4118: across the chunk boundary at row 4096
+        m_sub, c_sub = gp.predict_gradient(big[pts])
+    assert m_big.shape == (2, 700, 3) and c_big.shape == (2, 2, 700, 3, 2, 700, 3)
+    assert np.allclose(m_big[:, pts, :], m_sub, rtol=1e-13, atol=1e-15)
+    sub = c_big[:, :, pts][:, :, :, :, :, pts]
+    assert sub.shape == c_sub.shape and np.allclose(sub, c_sub, rtol=1e-12, atol=1e-14 * np.abs(c_sub).max())
 
 
 def test_covariant_golden_fixture():
