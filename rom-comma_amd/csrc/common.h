@@ -42,8 +42,10 @@ struct rcgp_handle_s {
   hipStream_t stream4 = nullptr;     // L^-1 kernels overlapped with the chain-bound tail of the Cholesky (rejected mode; masked like stream3 when that is)
   hipStream_t stream5 = nullptr;     // column work of the fine-grained panel chain (T2/G kernels, potrf.hip)
   hipStream_t stream6 = nullptr;     // the far part of that column work (block columns the next chain step does not read)
-  int prep_split = 2;                // the chain's critical step as k_prep1 + k_prep2 on several CUs (2: k_prep1 with 8 waves, 1: 4 waves) instead of k_prep_next on one (0) (RCGP_PSPLIT)
-  bool prep_attr_set = false;
+  int prep_split = 2;                // the chain's critical step: 3 = factor-only diagonal kernel + k_prep1s (substitution) + k_prep2, the 128x128 inverse
+                                     // off the critical path; 2 / 1 = k_prep1 (explicit inverse; 8 / 4 waves) + k_prep2; 0 = k_prep_next on one CU (RCGP_PSPLIT)
+  bool prep_attr_set = false, prep_s_attr_set = false;
+  bool short_k = true;               // K = 128 kernels of the panel chain request all their operand slabs up front (RCGP_SHORTK)
   bool chain_split = true;           // near / far split of the chain's column update (RCGP_SPLIT)
   hipEvent_t ev_inv = nullptr;       // last overlapped L^-1 kernel
   bool overlap_ok = false;            // RCGP_OVERLAP_INVERSE=1 overlaps L^-1 with the Cholesky tail (measured SLOWER: long L^-1 tiles hold the
@@ -197,6 +199,9 @@ int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double*
 int rc_launch_prep_next(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
 // the same in two kernels on 8 + 10 compute units (k_prep1 solves the tile, k_prep2 updates the diagonal block)
 int rc_launch_prep_split(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
+// the same with the tile solved by blocked forward substitution against L_jj itself (k_prep1s: needs only the 16x16 diagonal-block
+// inverses, which the factor-only diagonal kernel leaves in invL); the right-hand side is not touched
+int rc_launch_prep_subst(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL);
 // L^-1 by recursive doubling, level s: T = B * Ainv (lower-tri Ainv) for C-part row tiles [ti0, ti0+nti) of pairs
 // [pair0, pair0+npairs); X21 = -Cinv * T for whole pairs
 int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti0, int nti);
@@ -213,7 +218,7 @@ int rc_launch_vtv(rcgp_handle_s* h, int64_t rows_padded, const double* V, double
 
 // ---- potrf.hip
 int rc_potrf(rcgp_handle_s* h);                              // blocked Cholesky of A in place, w = L^-1 y, logdiag
-int rc_launch_diag(rcgp_handle_s* h, int64_t j);             // factor + invert diagonal block j (row/col offset), w_j
+int rc_launch_diag(rcgp_handle_s* h, int64_t j, int mode = 0);   // diagonal block at row/col offset j: 0 = factor + invert + w_j, 1 = factor only, 2 = invert + w_j
 
 // ---- solve.hip
 int rc_trtri_begin(rcgp_handle_s* h);                        // allocate Linv/S, reset the incremental schedule

@@ -19,6 +19,9 @@
                         // ds_read2_b64, which is banked over 32 dwords in groups of 16 consecutive lanes (16 rows of one k):
                         // stride 18 was two-way conflicted there (SQ_LDS_BANK_CONFLICT 5 cycles per LDS instruction), 17 is not
 #endif
+#ifndef RC_PF
+#define RC_PF 4           // register prefetch depth (slabs) of the short-K kernels of the panel chain
+#endif
 #define LDR 144         // row stride (doubles) of a KC=false LDS slab: [16][144]
 #define SLAB 2304       // doubles per operand slab (both layouts)
 #define GEMM_LDS (4 * SLAB)
@@ -122,6 +125,72 @@ __device__ __forceinline__ void gemm_mainloop(const double* __restrict__ A, int6
     slab_store<AKC, WN>(na, ra);
     slab_store<BKC, WN>(na + SLAB, rb);
     __syncthreads();
+  }
+}
+
+// The same product for a SHORT k-range (NK slabs of 16, NK = 8 on the panel chain: K = 128) with a PF-deep register prefetch: the
+// global loads of the first PF slabs are issued before anything is waited for (by the caller, ahead of its C-tile load, or here),
+// and slab kt + PF is requested as soon as slab kt has left its registers. The rolling two-stage prefetch of gemm_mainloop exposes
+// one memory round trip per slab when there are only eight of them and the workgroup has its CU to itself -- the panel-chain
+// kernels (panel solve, K = 128 updates) spent 25-40 us per 128^2 tile that way, most of it waiting. Costs 16 PF staging
+// registers per lane, so these kernels run one workgroup per CU.
+template <bool AKC, bool BKC, int WN, bool NEG, int NK, int PF>
+__device__ __forceinline__ void gemm_mainloop_pre(const double* __restrict__ A, int64_t lda, int64_t a0, const double* __restrict__ B,
+                                                  int64_t ldb, int64_t b0, int64_t k0, v4d (&acc)[4][Geo<WN>::NI], double* lds,
+                                                  RegsN<WN> (&ra)[PF], RegsN<WN> (&rb)[PF], bool loaded) {
+  constexpr int NI = Geo<WN>::NI;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = (wave / WN) * 64, wc = (wave % WN) * (16 * NI);
+  const int fr = lane & 15, fq = lane >> 4;
+  if (!loaded) {
+#pragma unroll
+    for (int kt = 0; kt < PF; ++kt) {
+      slab_load<AKC, WN>(A, lda, a0, k0 + 16 * kt, ra[kt]);
+      slab_load<BKC, WN>(B, ldb, b0, k0 + 16 * kt, rb[kt]);
+    }
+  }
+  slab_store<AKC, WN>(lds, ra[0]);
+  slab_store<BKC, WN>(lds + SLAB, rb[0]);
+  __syncthreads();
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    const double* la = lds + (kt & 1) * 2 * SLAB;
+    const double* lb = la + SLAB;
+    if (kt + PF < NK) {                                     // slot kt % PF went to LDS one iteration ago
+      slab_load<AKC, WN>(A, lda, a0, k0 + 16 * (kt + PF), ra[kt % PF]);
+      slab_load<BKC, WN>(B, ldb, b0, k0 + 16 * (kt + PF), rb[kt % PF]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double af[4], bf[NI];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const double v = frag_read<AKC>(la, wr + 16 * x + fr, 4 * s + fq);
+        af[x] = NEG ? -v : v;
+      }
+#pragma unroll
+      for (int x = 0; x < NI; ++x) bf[x] = frag_read<BKC>(lb, wc + 16 * x + fr, 4 * s + fq);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < NK) {
+      double* na = lds + ((kt + 1) & 1) * 2 * SLAB;
+      slab_store<AKC, WN>(na, ra[(kt + 1) % PF]);
+      slab_store<BKC, WN>(na + SLAB, rb[(kt + 1) % PF]);
+    }
+    __syncthreads();
+  }
+}
+
+template <bool AKC, bool BKC, int WN, int PF>
+__device__ __forceinline__ void slabs_load_first(const double* __restrict__ A, int64_t lda, int64_t a0, const double* __restrict__ B, int64_t ldb,
+                                                 int64_t b0, int64_t k0, RegsN<WN> (&ra)[PF], RegsN<WN> (&rb)[PF]) {
+#pragma unroll
+  for (int kt = 0; kt < PF; ++kt) {
+    slab_load<AKC, WN>(A, lda, a0, k0 + 16 * kt, ra[kt]);
+    slab_load<BKC, WN>(B, ldb, b0, k0 + 16 * kt, rb[kt]);
   }
 }
 
@@ -257,12 +326,35 @@ __global__ void RC_BOUNDS(WN) k_gemm_nt_sub(double* __restrict__ C, int64_t ldc,
   if (STAGED & 2) acc_store_staged<WN>(acc, Ct, ldc, lds); else acc_store<WN>(acc, Ct, ldc);
 }
 
+// K = 128 (the panel chain's column updates): every operand slab and the C tile requested before anything is waited for
+template <int WN>
+__global__ void __launch_bounds__(128 * WN) k_gemm_nt_sub_k128(double* __restrict__ C, int64_t ldc, const double* __restrict__ A, int64_t lda,
+                                                              const double* __restrict__ B, int64_t ldb, int64_t row0, int64_t col0) {
+  __shared__ double lds[GEMM_LDS];
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  if (col0 + (int64_t)tj * 128 > row0 + (int64_t)ti * 128) return;
+  RegsN<WN> ra[RC_PF], rb[RC_PF];
+  slabs_load_first<true, true, WN, RC_PF>(A, lda, (int64_t)ti * 128, B, ldb, (int64_t)tj * 128, 0, ra, rb);
+  v4d acc[4][Geo<WN>::NI];
+  double* Ct = C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128;
+  acc_load_staged<WN>(acc, Ct, ldc, lds);
+  gemm_mainloop_pre<true, true, WN, true, 8, RC_PF>(A, lda, (int64_t)ti * 128, B, ldb, (int64_t)tj * 128, 0, acc, lds, ra, rb, true);
+  acc_store_staged<WN>(acc, Ct, ldc, lds);
+}
+
 int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0) {
   if (m <= 0 || n <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)m * (double)n * (double)kk, true);
   const dim3 grid((unsigned)(n / 128), (unsigned)(m / 128)), block(128 * RC_WN);
-  RC_LAUNCH((k_gemm_nt_sub<RC_WN, 3>), grid, block, 0, C, ldc, A, lda, B, ldb, (int)kk, row0, col0);
+  // the up-front-prefetch variant runs one workgroup per CU: it wins while the launch is one round of tiles (latency-bound: near / far
+  // updates of the chain at N <= ~8000 and in the tail of larger systems: 46 -> 28 us per kernel) and loses when tiles queue for CUs
+  // (N = 28672 factorisation 138.5 -> 140.9 ms with it everywhere)
+  if (kk == 128 && h->short_k && (m / 128) * (n / 128) <= 512 && m <= 96 * 128) {
+    RC_LAUNCH((k_gemm_nt_sub_k128<RC_WN>), grid, block, 0, C, ldc, A, lda, B, ldb, row0, col0);
+  } else {
+    RC_LAUNCH((k_gemm_nt_sub<RC_WN, 3>), grid, block, 0, C, ldc, A, lda, B, ldb, (int)kk, row0, col0);
+  }
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -272,12 +364,17 @@ int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double
 // fused forward substitution of the right-hand side: rhs[rows] -= P_new * wj.
 // ---------------------------------------------------------------------------------------------------------------------
 // One 128-row tile of the panel solve: Pt (128 x 128) <- Pt * invL^T in place, rhs_t (128) -= Pt_new * wj.
-template <int WN>
+template <int WN, bool PRE = false>
 __device__ __forceinline__ void trsm_tile(double* Pt, int64_t ldp, const double* __restrict__ invL, double* rhs_t,
                                           const double* __restrict__ wj, double* lds, double (*rowsum)[128]) {
   v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
-  gemm_mainloop<true, true, WN>(Pt, ldp, 0, invL, 128, 0, 0, 128, acc, lds);
+  if (PRE) {
+    RegsN<WN> ra[RC_PF], rb[RC_PF];
+    gemm_mainloop_pre<true, true, WN, false, 8, RC_PF>(Pt, ldp, 0, invL, 128, 0, 0, acc, lds, ra, rb, false);
+  } else {
+    gemm_mainloop<true, true, WN>(Pt, ldp, 0, invL, 128, 0, 0, 128, acc, lds);
+  }
   RC_LANE_VARS(WN)
   double wv[NI_];
 #pragma unroll
@@ -316,6 +413,15 @@ __global__ void RC_BOUNDS(WN) k_trsm_panel(double* __restrict__ P, int64_t ldp, 
   __shared__ double rowsum[WN][128];
   const int ti = blockIdx.x;
   trsm_tile<WN>(P + (int64_t)ti * 128 * ldp, ldp, invL, rhs + (int64_t)ti * 128, wj, lds, rowsum);
+}
+
+template <int WN>
+__global__ void __launch_bounds__(128 * WN) k_trsm_panel_pre(double* __restrict__ P, int64_t ldp, const double* __restrict__ invL,
+                                                            double* __restrict__ rhs, const double* __restrict__ wj) {
+  __shared__ double lds[GEMM_LDS];
+  __shared__ double rowsum[WN][128];
+  const int ti = blockIdx.x;
+  trsm_tile<WN, true>(P + (int64_t)ti * 128 * ldp, ldp, invL, rhs + (int64_t)ti * 128, wj, lds, rowsum);
 }
 
 // Critical step of the fine-grained panel chain (potrf.hip), ONE workgroup: the tile T right below the diagonal block that has
@@ -476,6 +582,97 @@ __global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, do
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_prep1s: the tile below a freshly factored diagonal block solved WITHOUT the 128x128 inverse, by blocked forward substitution
+// against L_jj itself -- so that the chain's next step does not wait for the inversion (15 us of the diagonal kernel, now a kernel
+// of its own off the critical path). One workgroup per 16-row strip of the tile; with Y = X^T (128 x 16) the system is
+// L_jj Y = T^T, block by block  Y_c = inv(L_cc) (T^T_c - sum_{k<c} L_ck Y_k),  inv(L_cc) the 16x16 inverses the factor-only kernel
+// left in the diagonal blocks of invL. The whole recurrence stays in the registers of ONE wave: the C/D layout of a 16x16 MFMA
+// result (lane (j, q), register r: row q + 4 r, column j) IS the B-operand layout of the next four k-steps (k = 4 s + q: s = r), so
+// Y_k feeds the later products as it is, and T^T_c - ... goes into inv(L_cc) (...) the same way. 176 dependent MFMAs ~ 3 us.
+// The other waves only help to bring L_jj into LDS (all loads in flight before the first wait, as in k_prep1).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_prep1s(double* T, int64_t ld, const double* __restrict__ Ljj, const double* __restrict__ invL) {
+  extern __shared__ double sm1s[];                 // Ls[128][LP]: strictly lower 16-blocks of L_jj, inv(L_cc) in the diagonal blocks; Ts[16][LP]
+  double* Ls = sm1s;
+  double* Ts = Ls + 128 * LP;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
+  const int r0 = 16 * blockIdx.x;
+  constexpr int NLI = 128 * 64 / 256, NLT = 16 * 64 / 256;
+  double2 vi[NLI], vt[NLT];
+#pragma unroll
+  for (int q = 0; q < NLI; ++q) {
+    const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
+    vi[q] = make_double2(0.0, 0.0);
+    if (j2 <= i) vi[q] = ((i >> 4) == (j2 >> 4)) ? *reinterpret_cast<const double2*>(invL + i * 128 + j2)
+                                                 : *reinterpret_cast<const double2*>(Ljj + (int64_t)i * ld + j2);
+  }
+#pragma unroll
+  for (int q = 0; q < NLT; ++q) {
+    const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
+    vt[q] = *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2);
+  }
+#pragma unroll
+  for (int q = 0; q < NLI; ++q) {
+    const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
+    // (a pair never straddles two 16-blocks: j2 is even; the diagonal-block inverses are lower triangular with zeros above)
+    Ls[i * LP + j2] = vi[q].x;
+    Ls[i * LP + j2 + 1] = (j2 + 1 <= i) ? vi[q].y : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < NLT; ++q) {
+    const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
+    Ts[i * LP + j2] = vt[q].x;
+    Ts[i * LP + j2 + 1] = vt[q].y;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  v4d Y[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    v4d acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Ts[fr * LP + 16 * c + fq + 4 * r];          // (T^T)_c in the C layout: row fq + 4r, column fr
+#pragma unroll
+    for (int k = 0; k < c; ++k) {
+      double av[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) av[s2] = -Ls[(16 * c + fr) * LP + 16 * k + 4 * s2 + fq];   // -L_ck[i = fr][4 s + fq]
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Y[k][s2], acc, 0, 0, 0);
+    }
+    double xv[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) xv[s2] = Ls[(16 * c + fr) * LP + 16 * c + 4 * s2 + fq];        // inv(L_cc)[i = fr][4 s + fq]
+    v4d y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) y = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[s2], acc[s2], y, 0, 0, 0);
+    Y[c] = y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[(int64_t)(r0 + fr) * ld + 16 * c + fq + 4 * r] = y[r];        // X[fr][16 c + fq + 4 r] = Y_c[fq + 4 r][fr]
+  }
+}
+
+int rc_launch_prep_subst(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL) {
+  const size_t lds1 = (size_t)(128 * LP + 16 * LP) * sizeof(double), lds2 = (size_t)(64 * LP) * sizeof(double);
+  if (!h->prep_s_attr_set) {
+    RC_HIP(hipFuncSetAttribute((const void*)k_prep1s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    RC_HIP(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    h->prep_s_attr_set = true;
+  }
+  {
+    RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
+    RC_LAUNCH(k_prep1s, dim3(8), dim3(256), lds1, T, ld, Ljj, invL);
+    RC_HIP(hipGetLastError());
+  }
+  {
+    RcProfScope ps(h, RC_K_GEMM, 128.0 * 129.0 * 128.0, true);
+    RC_LAUNCH(k_prep2, dim3(10), dim3(256), lds2, (const double*)T, D, ld);
+    RC_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
 // T solved and rhs rows updated (k_prep1, which carries a pending h->launch_stop: the column work only needs the solved tile),
 // then the next diagonal block updated (k_prep2).
 int rc_launch_prep_split(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
@@ -513,7 +710,11 @@ int rc_launch_prep_next(rcgp_handle_s* h, double* T, double* D, int64_t ld, cons
 int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double* invL, int64_t m, double* rhs, const double* wj) {
   if (m <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, (double)m * 128.0 * 128.0, true);     // triangular: m*128*128 flops algorithmic
-  RC_LAUNCH(k_trsm_panel<RC_WN>, dim3((unsigned)(m / 128)), dim3(128 * RC_WN), 0, P, ldp, invL, rhs, wj);
+  if (h->short_k && m <= 96 * 128) {                       // (same rule as the K = 128 update: the latency-bound regime only)
+    RC_LAUNCH(k_trsm_panel_pre<RC_WN>, dim3((unsigned)(m / 128)), dim3(128 * RC_WN), 0, P, ldp, invL, rhs, wj);
+  } else {
+    RC_LAUNCH(k_trsm_panel<RC_WN>, dim3((unsigned)(m / 128)), dim3(128 * RC_WN), 0, P, ldp, invL, rhs, wj);
+  }
   RC_HIP(hipGetLastError());
   return 0;
 }

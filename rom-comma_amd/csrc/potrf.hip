@@ -332,6 +332,12 @@ __device__ __forceinline__ double xval(const double* S, const double* Xd, int i,
 }
 
 
+// MODE 0: the whole job (factor, invert, w_j). MODE 1: factor only -- L_jj, log L_ii and the eight 16x16 diagonal-block inverses
+// (written into the diagonal 16-blocks of invL) -- which is all the NEXT chain step needs (k_prep1s solves the tile below by
+// substitution): the 128x128 inverse and w_j are 15 us of this kernel and come off the critical path. MODE 2: the rest, as a kernel
+// of its own on the column-work stream: reads L_jj and the diagonal-block inverses back, completes the right-hand side rows of
+// this block (rhs_j -= L(j, j-1) w_{j-1}: the block row the chain no longer updates), inverts, emits invL and w_j.
+template <int MODE>
 __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
                                                double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
   extern __shared__ double S[];                    // [128][LS], then Xd[8][16][XS], rsd[128], rv[128]
@@ -361,10 +367,36 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
       S[i * LS + j + 1] = (j + 1 <= i) ? v[q].y : 0.0;
     }
   }
-  if (t < 128) rv[t] = rhs[j0 + t];
+  if (MODE == 0 && t < 128) rv[t] = rhs[j0 + t];
+  if (MODE == 2) {
+    // the diagonal-block inverses of the factor-only kernel, and this block's right-hand side rows brought up to date with the tile
+    // to the left (4 lanes per row, 16-byte loads all in flight)
+    for (int e = t; e < 8 * 16 * 16; e += 512) {
+      const int c = e >> 8, i = (e >> 4) & 15, j = e & 15;
+      Xd[(c * 16 + i) * XS + j] = invL[(16 * c + i) * 128 + 16 * c + j];
+    }
+    const int i = t >> 2, h4 = t & 3;
+    double sacc = 0.0;
+    if (j0 > 0) {
+      const double* Trow = A + (j0 + i) * ld + (j0 - 128);
+      const double* wprev = rhs + (j0 - 128);
+      double2 tv[16], wv2[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        tv[q] = *reinterpret_cast<const double2*>(Trow + 8 * q + 2 * h4);
+        wv2[q] = *reinterpret_cast<const double2*>(wprev + 8 * q + 2 * h4);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sacc = __builtin_fma(tv[q].y, wv2[q].y, __builtin_fma(tv[q].x, wv2[q].x, sacc));
+      sacc += __shfl_xor(sacc, 1);
+      sacc += __shfl_xor(sacc, 2);
+    }
+    if (h4 == 0) rv[i] = rhs[j0 + i] - sacc;
+  }
   __syncthreads();
   RC_T(1);
 
+  if (MODE != 2) {
   // ------------------------------------------------------------------ blocked Cholesky
   // Iteration c: (a) trailing update with block column c-1 of the lower tiles (rb, cb), c <= cb <= rb -- tile (c, c) goes to
   // wave 0, which then factors that pivot block while the other waves finish the remaining tiles; (b) panel below the pivot block.
@@ -424,6 +456,15 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
   }
   if (t < 128) logdiag[j0 + t] = -log(rsd[t]);
   RC_T(19);
+  if (MODE == 1) {                                   // the diagonal-block inverses, where the substitution kernel and MODE 2 find them
+    for (int e = t; e < 8 * 16 * 8; e += 512) {
+      const int c = e >> 7, i = (e >> 3) & 15, j = (e & 7) * 2;
+      *reinterpret_cast<double2*>(invL + (16 * c + i) * 128 + 16 * c + j) =
+          make_double2(Xd[(c * 16 + i) * XS + j], Xd[(c * 16 + i) * XS + j + 1]);
+    }
+    return;
+  }
+  }  // MODE != 2
 
 #ifndef RC_DIAG2_NO_INVERSE
   // ------------------------------------------------------------------ inverse by recursive doubling
@@ -518,18 +559,26 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
   RC_T(23);
 }
 
-int rc_launch_diag(rcgp_handle_s* h, int64_t j) {
-  RcProfScope ps(h, RC_K_DIAG, 128.0 * 128.0 * 128.0 / 3.0, true);
+int rc_launch_diag(rcgp_handle_s* h, int64_t j, int mode) {
+  RcProfScope ps(h, RC_K_DIAG, mode == 2 ? 0.0 : 128.0 * 128.0 * 128.0 / 3.0, true);
   double* inv = h->invdiag + (j / 128) * 128 * 128;
   if (h->diag_variant == 1) {
     RC_LAUNCH(k_diag, dim3(1), dim3(512), 0, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
   } else {
     const size_t lds = (size_t)(128 * LS + 8 * 16 * XS + 256 + 32 + 256) * sizeof(double);
     if (!h->diag_attr_set) {                                   // per handle = per device (the attribute is device state)
-      RC_HIP(hipFuncSetAttribute((const void*)k_diag2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      RC_HIP(hipFuncSetAttribute((const void*)k_diag2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      RC_HIP(hipFuncSetAttribute((const void*)k_diag2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      RC_HIP(hipFuncSetAttribute((const void*)k_diag2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       h->diag_attr_set = true;
     }
-    RC_LAUNCH(k_diag2, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
+    if (mode == 1) {
+      RC_LAUNCH(k_diag2<1>, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
+    } else if (mode == 2) {
+      RC_LAUNCH(k_diag2<2>, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
+    } else {
+      RC_LAUNCH(k_diag2<0>, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
+    }
   }
   RC_HIP(hipGetLastError());
   return 0;
@@ -605,13 +654,23 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
   bool near_waited = false, far_waited = false;                  // this panel's wait for the previous panel's window piece
   int64_t u0_prev = 0;                                           // first column of that piece
   const bool ext = h->ext_events && !h->profiling;              // (the profiling bracket records its own events around a launch)
+  // late: the diagonal kernel only factors (k_diag2<1>); the 128x128 inverse and w_j follow on the column-work stream (k_diag2<2>, ahead
+  // of the panel solve that needs them) and the chain's tile is solved by substitution (k_prep1s)
+  const bool late = (h->prep_split == 3) && h->diag_variant != 1;
   for (int64_t j = 0; j < Np; j += 128) {
     const int64_t below = Np - (j + 128);
     hipEvent_t eD = nullptr, eP, eG;
-    if (below > 0 && (rc = next_event(h, &eD))) return rc;
+    if ((below > 0 || late) && (rc = next_event(h, &eD))) return rc;
     h->launch = C;
     if (ext) h->launch_stop = eD;
-    if ((rc = rc_launch_diag(h, j)) || (rc = flush_stop(h))) return rc;
+    if ((rc = rc_launch_diag(h, j, late ? 1 : 0)) || (rc = flush_stop(h))) return rc;
+    if (late) {
+      if (!ext) RC_HIP(hipEventRecord(eD, C));
+      RC_HIP(hipStreamWaitEvent(B, eD, 0));
+      h->launch = B;
+      if ((rc = rc_launch_diag(h, j, 2))) return rc;              // inverse + w_j (+ this block's rhs rows from the tile to its left)
+      h->launch = C;
+    }
     if (below <= 0) break;
     const int64_t pend = (j / NB + 1) * NB;                      // end of the panel block j belongs to
     const int64_t cend = (pend + EXT < Np) ? pend + EXT : Np;    // G(j) covers the block columns [j + 128, cend)
@@ -619,12 +678,16 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     double* P = h->A + (j + 128) * Np + j;                       // rows below the diagonal block, 128 columns
     const double* inv = h->invdiag + (j / 128) * 128 * 128;
     if ((rc = next_event(h, &eP)) || (rc = next_event(h, &eG))) return rc;
-    if (!ext) RC_HIP(hipEventRecord(eD, C));
-    RC_HIP(hipStreamWaitEvent(B, eD, 0));
+    if (!late) {
+      if (!ext) RC_HIP(hipEventRecord(eD, C));
+      RC_HIP(hipStreamWaitEvent(B, eD, 0));
+    }
     if (eG_prev) RC_HIP(hipStreamWaitEvent(C, eG_prev, 0));
     if (first_of_panel && eU1_prev && h->chain_ext < 2) RC_HIP(hipStreamWaitEvent(C, eU1_prev, 0));   // P touches column j + 128 >= u0
     if (ext) h->launch_stop = eP;                                 // (with the split: taken by k_prep1 -- the column work needs the solved tile only)
-    if (h->prep_split)
+    if (late)
+      rc = rc_launch_prep_subst(h, P, h->A + (j + 128) * Np + (j + 128), Np, h->A + j * Np + j, inv);
+    else if (h->prep_split)
       rc = rc_launch_prep_split(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j);
     else
       rc = rc_launch_prep_next(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j);
@@ -679,6 +742,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
         return rc;
       if (!ext) RC_HIP(hipEventRecord(eG, B));
     } else {
+      if (late) RC_HIP(hipStreamWaitEvent(B, eP, 0));            // the last block's inverse kernel reads the tile P(j) solves
       RC_HIP(hipEventRecord(eG, B));
     }
     eG_prev = eG;
