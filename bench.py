@@ -174,17 +174,44 @@ def main():
                                                                         # factor): its work buffers (L^-1, scratch) exist before the timed region
     slices = all_slices(M)
     last = {}
-    counter = {'s': 0, 'nfev': 0}
+    counter = {'s': 0, 'nfev': 0, 'lib_s': 0.0, 'sobol_s': 0.0}
     gp = handles[units[-1]]                          # the handle of the last timed step: profiled launches, stand-alone stages
+
+    class Timed:
+        """The handle with the wall time spent inside the library calls of a fit (hyper-parameter upload + evaluation, the host's wait
+        for the GPU included) added up: what is left of a step is the host's own share (SciPy's L-BFGS-B, the softplus chain rule)."""
+
+        def __init__(self, gp):
+            self._gp = gp
+            self.M = gp.M
+
+        def set_hyper(self, *a):
+            t = time.perf_counter()
+            self._gp.set_hyper(*a)
+            counter['lib_s'] += time.perf_counter() - t
+
+        def lml_grad(self):
+            t = time.perf_counter()
+            out = self._gp.lml_grad()
+            counter['lib_s'] += time.perf_counter() - t
+            return out
+
+        def lml(self):
+            t = time.perf_counter()
+            out = self._gp.lml()
+            counter['lib_s'] += time.perf_counter() - t
+            return out
 
     def step(profiled=False):
         gp = handles[units[counter['s']]]
         counter['s'] += 1
-        fit = fit_lbfgsb(gp, 5.0 * np.ones(M), 2.0, 0.02)
+        fit = fit_lbfgsb(Timed(gp), 5.0 * np.ones(M), 2.0, 0.02)
         counter['nfev'] += int(fit['nfev'])
         if profiled:
             gp.set_profiling(True)
+        t_sobol = time.perf_counter()
         V = gp.sobol_closed(slices)
+        counter['sobol_s'] += time.perf_counter() - t_sobol
         row = np.concatenate([sobol_indices(V, M), fit['lengthscales'], [fit['variance'], fit['noise'], fit['log_marginal'], fit['nfev']]])
         table = dist.all_gather_rows(row[None, :], world, [rank])      # the one collective: every rank's indices
         last.update(fit=fit, V=V, table=table)
@@ -195,7 +222,7 @@ def main():
         h.profile_reset()
         h.sync()
     dist.barrier()
-    counter['nfev'] = 0
+    counter['nfev'], counter['lib_s'], counter['sobol_s'] = 0, 0.0, 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         # Per-launch HIP events cost ~5 % (profiled dispatches, marker packets on the panel chain, harvesting), so by default
@@ -252,7 +279,9 @@ def main():
                                    f'total indices, N={N}, M={M}, ' + (f'L=1, fold (r + step) mod {K_folds} of an {K_folds}-fold split on GPU r' if args.shard == 'folds' else
                                                           f'output r of {max(8, world)} independent outputs on one design per GPU'),
                        'N': N, 'M': M, 'lbfgs_evaluations_last_step': nfev, 'lbfgs_evaluations_timed_steps': nfev_total,
-                       'ms_per_evaluation_incl_host': 1e3 * elapsed / max(nfev_total, 1), 'parallelism': f'{args.shard[:-1]}-per-gpu x{world}',
+                       'ms_per_evaluation_incl_host': 1e3 * elapsed / max(nfev_total, 1),
+                       'ms_per_step_inside_library_calls': 1e3 * (counter['lib_s'] + counter['sobol_s']) / args.steps,
+                       'ms_per_step_host_only': 1e3 * (elapsed - counter['lib_s'] - counter['sobol_s']) / args.steps, 'parallelism': f'{args.shard[:-1]}-per-gpu x{world}',
                        'log_marginal': last['fit']['log_marginal']},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic(N, M),

@@ -45,6 +45,8 @@ struct rcgp_handle_s {
   int prep_split = 2;                // the chain's critical step: 3 = factor-only diagonal kernel + k_prep1s (substitution) + k_prep2, the 128x128 inverse
                                      // off the critical path; 2 / 1 = k_prep1 (explicit inverse; 8 / 4 waves) + k_prep2; 0 = k_prep_next on one CU (RCGP_PSPLIT)
   bool prep_attr_set = false, prep_s_attr_set = false;
+  int grad_order = 0;                // k_grad tile order: 0 = heavy-first rows; 1 = 8 x 8 super-blocks per XCD with a common k start (measured: HBM reads -7 %,
+                                     // time +13 % -- prefetching workgroups drift apart) (RCGP_GRAD_ORDER)
   bool short_k = true;               // K = 128 kernels of the panel chain request all their operand slabs up front (RCGP_SHORTK)
   bool chain_split = true;           // near / far split of the chain's column update (RCGP_SPLIT)
   hipEvent_t ev_inv = nullptr;       // last overlapped L^-1 kernel

@@ -778,18 +778,40 @@ int rc_launch_trtri_X(rcgp_handle_s* h, int64_t s, int pair0, int npairs) {
 //   Wij = alpha_i alpha_j - Kinv_ij ; G_m = sum Wij Kij (z_im - z_jm)^2 ; G_var = sum Wij Kij ; G_noise = tr W
 // K^-1 is never written: each lower tile is reduced in the epilogue to M+2 partial sums (row blockIdx of h->partial).
 // ---------------------------------------------------------------------------------------------------------------------
+// Tile order (order = 1): 8 x 8 super-blocks of tiles, ONE PER XCD AT A TIME. Blocks are dealt round-robin over the 8 XCDs (block b and
+// b + 8 share one: MI355X_MICROARCH.md, workgroup dispatch -- a speed assumption only), so the 64 tiles of a super-block are given to
+// blocks with equal b % 8: the 64 workgroups resident on an XCD then stream 8 + 8 operand panels through that XCD's L2 instead of
+// 64 + 64, PROVIDED they walk k together -- so every tile of a super-block starts at the block's first k (I * 1024) instead of its
+// own ti * 128: the extra slabs multiply the zero upper triangle of L^-1 (zeroed once at allocation), add exactly +0 and cost <= 7/8
+// of a tile row per super-row (~5 % more slab iterations); all 64 tiles then have the same trip count and finish together.
+// Super-blocks go out heaviest first (I ascending = longest k-range), every 8th one to the same XCD. Results are bit-identical.
 template <int LZ, int WN>
 __global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld, int64_t Np, int64_t N, int M, const double* __restrict__ Z,
                                      const double* __restrict__ sq, const double* __restrict__ alpha, double var,
-                                     double* __restrict__ partial) {
+                                     double* __restrict__ partial, int order, int nsb) {
   constexpr int ZL = 2 * 128 * LZ;
   constexpr int NW = 2 * WN;                                  // waves per workgroup
   __shared__ double lds[(GEMM_LDS > ZL ? GEMM_LDS : ZL) + NW * (RC_MAX_M + 2)];
   int ti, tj;
-  tri_decode(blockIdx.x, ti, tj);
+  int64_t kstart;
+  if (order == 0) {
+    tri_decode(blockIdx.x, ti, tj);
+    kstart = (int64_t)ti * 128;
+  } else {
+    const int b = blockIdx.x, g = b & 7, q = b >> 3;
+    const int sb = (q >> 6) * 8 + g, t64 = q & 63;
+    if (sb >= nsb) return;
+    int I, J;
+    tri_decode(sb, I, J);
+    ti = I * 8 + (t64 >> 3);
+    tj = J * 8 + (t64 & 7);
+    if ((int64_t)ti * 128 >= Np || tj > ti) return;
+    kstart = (int64_t)I * 1024;
+  }
+  const int64_t tile_id = (int64_t)ti * (ti + 1) / 2 + tj;     // row of `partial`
   v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
-  gemm_mainloop<false, false, WN>(Linv, ld, (int64_t)ti * 128, Linv, ld, (int64_t)tj * 128, (int64_t)ti * 128, Np, acc, lds);
+  gemm_mainloop<false, false, WN>(Linv, ld, (int64_t)ti * 128, Linv, ld, (int64_t)tj * 128, kstart, Np, acc, lds);
   RC_LANE_VARS(WN)
   double* zi = lds;
   double* zj = lds + 128 * LZ;
@@ -864,7 +886,7 @@ __global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) s += red[w * (RC_MAX_M + 2) + m];      // fixed order: bit-reproducible
-    partial[(int64_t)blockIdx.x * (M + 2) + m] = s;
+    partial[tile_id * (M + 2) + m] = s;
   }
 }
 
@@ -875,12 +897,16 @@ int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
   if (rc) return rc;
   const double np = (double)h->Np;
   RcProfScope ps(h, RC_K_GRAD, np * np * np / 3.0);
+  const int64_t TS = (T + 7) / 8;                                 // super-rows of 8 tile rows
+  const int nsb = (int)(TS * (TS + 1) / 2);
+  const int order = h->grad_order;
+  const unsigned grid = order ? (unsigned)(((nsb + 7) / 8) * 8 * 64) : (unsigned)nb;
   if (h->M <= 32)
-    hipLaunchKernelGGL((k_grad<33, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
-                       h->sq, h->alpha, h->var, h->partial);
+    hipLaunchKernelGGL((k_grad<33, RC_WN>), dim3(grid), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
+                       h->sq, h->alpha, h->var, h->partial, order, nsb);
   else
-    hipLaunchKernelGGL((k_grad<65, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
-                       h->sq, h->alpha, h->var, h->partial);
+    hipLaunchKernelGGL((k_grad<65, RC_WN>), dim3(grid), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
+                       h->sq, h->alpha, h->var, h->partial, order, nsb);
   RC_HIP(hipGetLastError());
   *nrows = (int)nb;
   return 0;

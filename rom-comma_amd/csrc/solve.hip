@@ -26,7 +26,12 @@ __global__ void k_put_diag(double* __restrict__ W, int64_t ld, const double* __r
 // everything that has become runnable; the Cholesky calls it after every panel, rc_trtri() finishes with done_rows = Np.
 int rc_trtri_begin(rcgp_handle_s* h) {
   const int64_t Np = h->Np;
-  if (!h->Linv) RC_HIP(hipMalloc(&h->Linv, (size_t)Np * Np * sizeof(double)));
+  if (!h->Linv) {
+    RC_HIP(hipMalloc(&h->Linv, (size_t)Np * Np * sizeof(double)));
+    // the strictly upper 128-blocks are never written afterwards: zero once, so that k_grad may run a tile's k-range from the start of
+    // its super-block (multiplying zeros) instead of from its own diagonal
+    RC_HIP(hipMemsetAsync(h->Linv, 0, (size_t)Np * Np * sizeof(double), h->stream));
+  }
   if (!h->S) RC_HIP(hipMalloc(&h->S, (size_t)Np * Np * sizeof(double)));
   int levels = 0;
   for (int64_t s = 128; s < Np; s *= 2) ++levels;
