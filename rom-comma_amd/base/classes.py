@@ -1,6 +1,13 @@
-"""Frame / Data / Model: every model parameter is a small DataFrame mirrored to ``<folder>/<field>.csv`` the moment it
-changes, and every model owns a ``meta.json``. This is the reference's checkpoint/resume mechanism (base/classes.py:34-321);
-the on-disk layout and file formats are kept so folders written by either implementation can be read by the other.
+"""The checkpoint / resume mechanism behind every model of the plugin API (contract: reference base/classes.py:34-321, SURVEY.md
+Appendix D): a model is a folder; each of its parameters is a small table mirrored to ``<folder>/<field>.csv`` the moment it is
+assigned; ``meta.json`` (indent 8) holds the options. Folders written by the reference can be read here and vice versa:
+parameter tables are ``DataFrame.to_csv`` with the default integer header and index column, read back with ``index_col=0``.
+
+Three layers:
+    ``Frame``  one table <-> one csv file (path given WITHOUT the suffix);
+    ``Data``   the named tables of one folder; subclasses declare them through an inner ``NamedTuple`` whose defaults are the defaults
+               of the parameters;
+    ``Model``  folder + ``meta.json`` + a ``Data``.
 """
 from __future__ import annotations
 
@@ -8,72 +15,82 @@ import json
 import shutil
 from abc import ABC, abstractmethod
 from pathlib import Path
-from typing import Any, Dict, Iterable, NamedTuple, Tuple, Type
+from typing import Any, Dict, Iterable, NamedTuple, Tuple
 
 import numpy as np
 import pandas as pd
 
+_CSV_SUFFIX = '.csv'
+_META_INDENT = 8                       # base/classes.py:292-295
+
+
+def _fresh_folder(folder: Path | str) -> Path:
+    """``folder`` emptied (created if need be)."""
+    folder = Path(folder)
+    if folder.exists():
+        shutil.rmtree(folder, ignore_errors=True)
+    folder.mkdir(mode=0o777, parents=True, exist_ok=False)
+    return folder
+
 
 class Frame:
-    """A pandas DataFrame backed by ``<csv>.csv``. ``csv`` is given WITHOUT the suffix (base/classes.py:37,69)."""
+    """One parameter table and its csv file."""
 
     def __init__(self, csv: Path | str, data=None, index=None, columns=None, dtype=None, copy=None, **kwargs: Any):
-        """``data is None`` reads the file (index_col=0 unless overridden); anything else is stored and written at once.
-        ``kwargs`` go to ``pd.read_csv`` or ``DataFrame.to_csv`` respectively (base/classes.py:102-123)."""
+        """Without ``data`` the file is read (``kwargs`` -> ``pd.read_csv``, ``index_col=0`` unless overridden); with it the table is
+        built like ``pd.DataFrame(data, index, columns, dtype, copy)`` and written at once (``kwargs`` -> ``to_csv``, remembered)."""
         self.csv = Path(csv)
-        self._write_options: Dict[str, Any] = {}
+        self._to_csv_options: Dict[str, Any] = {}
         if data is None:
-            self._df = pd.read_csv(self._file, **({'index_col': 0} | kwargs))
-        else:
-            self._df = pd.DataFrame(data, index, columns, dtype, copy)
-            self.write(**kwargs)
+            options = {'index_col': 0}
+            options.update(kwargs)
+            self._table = pd.read_csv(self.path, **options)
+            return
+        self._table = pd.DataFrame(data, index, columns, dtype, copy)
+        self.write(**kwargs)
 
     @property
-    def _file(self) -> Path:
-        return self.csv.with_suffix(f'{self.csv.suffix}.csv')
+    def path(self) -> Path:
+        """The file itself: ``csv`` with '.csv' appended to whatever suffix the name already carries ('a.b' -> 'a.b.csv')."""
+        return self.csv.with_suffix(self.csv.suffix + _CSV_SUFFIX)
 
+    # -- views of the table
     @property
     def df(self) -> pd.DataFrame:
-        return self._df
+        return self._table
 
-    @property
-    def np(self) -> np.ndarray:
-        return self._df.values
+    def _get_values(self) -> np.ndarray:
+        return self._table.values
 
-    @np.setter
-    def np(self, value):
-        self._df.iloc[:, :] = value
+    def _set_values(self, value) -> None:
+        self._table.iloc[:, :] = value
         self.write()
 
-    @property
-    def tf(self) -> np.ndarray:
-        """The reference returns a tf.Tensor here (base/classes.py:52-54); this backend has no TensorFlow: a NumPy view."""
-        return self.np
+    np = property(_get_values, _set_values, doc='The values; assignment writes through to the file.')
+    tf = property(_get_values, lambda self, value: self._set_values(np.asarray(value)),
+                  doc='The reference returns a tf.Tensor here (base/classes.py:52-54); this backend has no TensorFlow: the same NumPy view.')
 
-    @tf.setter
-    def tf(self, value):
-        self.np = np.asarray(value)
+    def __call__(self, *args, **kwargs) -> np.ndarray:
+        return self._get_values()
 
+    # -- persistence
     def write(self, **kwargs: Any) -> 'Frame':
-        """Write to csv; the options are remembered for later writes (base/classes.py:61-70)."""
-        self._write_options |= kwargs
-        self._df.to_csv(self._file, **self._write_options)
+        """To csv; options given once stay in force for later writes (the GSA tables keep their ``float_format`` that way)."""
+        self._to_csv_options.update(kwargs)
+        self._table.to_csv(self.path, **self._to_csv_options)
         return self
 
     def broadcast_value(self, target_shape: Tuple[int, int], is_diagonal: bool = True) -> 'Frame':
-        """Broadcast to ``target_shape``; a square target keeps only the diagonal when ``is_diagonal``. Raises IndexError when
-        the value cannot be broadcast (base/classes.py:72-89)."""
+        """Grow the table to ``target_shape`` by NumPy broadcasting and write it. A target with more than one row keeps only its
+        diagonal when ``is_diagonal`` (independent parameters promoted to a covariance-shaped table). What cannot be broadcast --
+        shrinking included -- raises IndexError."""
         try:
-            values = np.array(np.broadcast_to(self.np, target_shape))
-        except ValueError:
-            raise IndexError(f'{self!r} has shape {self.df.shape} which cannot be broadcast to {target_shape}.')
-        if is_diagonal and target_shape[0] > 1:
-            values = np.diag(np.diagonal(values))
-        self._df = pd.DataFrame(values)
+            grown = np.broadcast_to(self._get_values(), target_shape)
+        except ValueError as error:
+            raise IndexError(f'{self!r} has shape {self._table.shape} which cannot be broadcast to {target_shape}.') from error
+        grown = np.diag(np.diagonal(grown)) if (is_diagonal and target_shape[0] > 1) else np.array(grown)
+        self._table = pd.DataFrame(grown)
         return self.write()
-
-    def __call__(self, *args, **kwargs) -> np.ndarray:
-        return self.np
 
     def __repr__(self) -> str:
         return str(self.csv)
@@ -83,21 +100,12 @@ class Frame:
 
 
 class Data(ABC):
-    """A NamedTuple of Frames living in one folder (base/classes.py:127-236). Subclasses override ``NamedTuple``."""
+    """The tables of one folder, addressed by field name through ``frames`` (an instance of the subclass's ``NamedTuple``)."""
 
     class NamedTuple(NamedTuple):
         NotImplemented: Any = np.atleast_2d('NotImplemented')
 
-    def __init__(self, folder: Path | str, **kwargs: Any):
-        folder = Path(folder)
-        self._folder = folder if folder.exists() else self.empty(folder)
-        self._frames = None
-        self.replace(**self.NamedTuple(**kwargs)._asdict())
-
-    @classmethod
-    def make(cls, iterable: Iterable):
-        return cls.NamedTuple._make(iterable)
-
+    # -- what a subclass declares
     @classmethod
     @property
     def fields(cls) -> Tuple[str, ...]:
@@ -108,16 +116,34 @@ class Data(ABC):
     def field_defaults(cls) -> Dict[str, Any]:
         return cls.NamedTuple._field_defaults
 
-    def asdict(self) -> Dict[str, Any]:
-        return self._frames._asdict()
+    @classmethod
+    def make(cls, iterable: Iterable):
+        return cls.NamedTuple._make(iterable)
+
+    # -- construction
+    def __init__(self, folder: Path | str, **kwargs: Any):
+        """Tables from ``kwargs`` (defaults for the rest), written under ``folder``; a folder that does not exist yet is created."""
+        folder = Path(folder)
+        self._folder = folder if folder.exists() else _fresh_folder(folder)
+        self._frames = None
+        self.replace(**self.NamedTuple(**kwargs)._asdict())
+
+    @classmethod
+    def read(cls, folder: Path | str, **kwargs: Any) -> 'Data':
+        """Every field read from ``folder``, except those given in ``kwargs``, which are written instead."""
+        folder = Path(folder)
+        tables = {name: Frame(folder / name, kwargs.get(name)) for name in cls.fields}
+        return cls(folder, **tables)
 
     def replace(self, **kwargs: Any) -> 'Data':
-        """Assign fields; each assignment is written to ``<folder>/<field>.csv`` immediately (base/classes.py:155-160)."""
-        frames = {key: (value if isinstance(value, Frame) else Frame(self._folder / key, np.atleast_2d(np.asarray(value))))
-                  for key, value in kwargs.items()}
-        self._frames = self.NamedTuple(**frames) if self._frames is None else self._frames._replace(**frames)
+        """Assign fields. A value that is not already a ``Frame`` becomes one -- i.e. is written to ``<folder>/<field>.csv`` now."""
+        as_frames = {}
+        for name, value in kwargs.items():
+            as_frames[name] = value if isinstance(value, Frame) else Frame(self._folder / name, np.atleast_2d(np.asarray(value)))
+        self._frames = self.NamedTuple(**as_frames) if self._frames is None else self._frames._replace(**as_frames)
         return self
 
+    # -- access
     @property
     def folder(self) -> Path:
         return self._folder
@@ -125,6 +151,9 @@ class Data(ABC):
     @property
     def frames(self):
         return self._frames
+
+    def asdict(self) -> Dict[str, Any]:
+        return self._frames._asdict()
 
     def __call__(self, *args, **kwargs):
         return self._frames
@@ -135,40 +164,34 @@ class Data(ABC):
     def __str__(self) -> str:
         return self._folder.name
 
-    @classmethod
-    def read(cls, folder: Path | str, **kwargs: Any) -> 'Data':
-        """Read every field from ``folder``; ``kwargs`` override fields after reading (base/classes.py:203-215)."""
-        folder = Path(folder)
-        return cls(folder, **{field: Frame(folder / field, kwargs.get(field, None)) for field in cls.fields})
-
+    # -- folders
     def move(self, dst_folder: Path | str) -> 'Data':
-        dst = self.empty(dst_folder)
-        for key, frame in self.asdict().items():
-            Frame(dst / key, frame.df)
-        self._folder = dst
+        """Re-home the tables in a fresh ``dst_folder``."""
+        target = _fresh_folder(dst_folder)
+        for name, frame in self.asdict().items():
+            Frame(target / name, frame.df)
+        self._folder = target
         return self
 
     @staticmethod
     def delete(folder: Path | str) -> Path:
-        folder = Path(folder)
-        shutil.rmtree(folder, ignore_errors=True)
-        return folder
+        shutil.rmtree(Path(folder), ignore_errors=True)
+        return Path(folder)
 
     @staticmethod
     def empty(folder: Path | str) -> Path:
-        folder = Data.delete(folder)
-        folder.mkdir(mode=0o777, parents=True, exist_ok=False)
-        return folder
+        return _fresh_folder(folder)
 
     @staticmethod
     def copy(src_folder: Path | str, dst_folder: Path | str) -> Path:
-        dst_folder = Data.delete(dst_folder)
-        shutil.copytree(src=src_folder, dst=dst_folder)
-        return dst_folder
+        """Destructive copy of a whole model folder (the isotropic -> anisotropic warm start of ``run.gpr``)."""
+        target = Data.delete(dst_folder)
+        shutil.copytree(src=src_folder, dst=target)
+        return target
 
 
 class Model(ABC):
-    """Folder + ``meta.json`` + ``Data`` (base/classes.py:239-321)."""
+    """A folder with options (``meta.json``) and parameters (``Data``); ``calibrate`` is what a concrete model must supply."""
 
     class Data(Data):
         class NamedTuple(NamedTuple):
@@ -177,18 +200,25 @@ class Model(ABC):
     @classmethod
     @property
     def META(cls) -> Dict[str, Any]:
+        """Default options."""
         return {}
 
     @abstractmethod
     def __init__(self, folder: Path | str, read_data: bool = False, **kwargs: Any):
+        """``read_data``: parameters come from the folder's csv files and ``kwargs`` override them; otherwise the folder is made
+        if need be and the parameters are ``kwargs`` over the defaults."""
         self._folder = Path(folder)
         self._meta_json = self._folder / 'meta.json'
+        self._implementation = None
         if read_data:
             self._data = self.Data.read(self._folder).replace(**kwargs)
-        else:
-            self._folder.mkdir(mode=0o777, parents=True, exist_ok=True)
-            self._data = self.Data(self._folder, **kwargs)
-        self._implementation = None
+            return
+        self._folder.mkdir(mode=0o777, parents=True, exist_ok=True)
+        self._data = self.Data(self._folder, **kwargs)
+
+    @abstractmethod
+    def calibrate(self, method: str, **kwargs) -> Dict[str, Any]:
+        raise NotImplementedError('base.calibrate() must never be called.')
 
     @property
     def folder(self) -> Path:
@@ -202,17 +232,11 @@ class Model(ABC):
     def data(self, value: Data):
         self._data = value
 
-    @abstractmethod
-    def calibrate(self, method: str, **kwargs) -> Dict[str, Any]:
-        raise NotImplementedError('base.calibrate() must never be called.')
-
     def read_meta(self) -> Dict[str, Any]:
-        with open(self._meta_json, mode='r') as file:
-            return json.load(file)
+        return json.loads(self._meta_json.read_text())
 
     def write_meta(self, meta: Dict[str, Any]):
-        with open(self._meta_json, mode='w') as file:
-            json.dump(meta, file, indent=8)
+        self._meta_json.write_text(json.dumps(meta, indent=_META_INDENT))
 
     def __repr__(self) -> str:
         return str(self._folder)

@@ -211,6 +211,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   if (const char* e = getenv("RCGP_PSPLIT")) h->prep_split = atoi(e);
   if (const char* e = getenv("RCGP_SHORTK")) h->short_k = (e[0] != '0');
   if (const char* e = getenv("RCGP_GRAD_ORDER")) h->grad_order = atoi(e);
+  if (const char* e = getenv("RCGP_T2WAIT")) h->t2_after_p = (e[0] != '0');
   if (const char* e = getenv("RCGP_INV_EVERY")) {
     const int x = atoi(e);
     if (x >= 1) h->inv_every = x;

@@ -47,6 +47,7 @@ struct rcgp_handle_s {
   bool prep_attr_set = false, prep_s_attr_set = false;
   int grad_order = 0;                // k_grad tile order: 0 = heavy-first rows; 1 = 8 x 8 super-blocks per XCD with a common k start (measured: HBM reads -7 %,
                                      // time +13 % -- prefetching workgroups drift apart) (RCGP_GRAD_ORDER)
+  bool t2_after_p = false;           // the panel solve waits for the chain's solved tile instead of the diagonal kernel (RCGP_T2WAIT)
   bool short_k = true;               // K = 128 kernels of the panel chain request all their operand slabs up front (RCGP_SHORTK)
   bool chain_split = true;           // near / far split of the chain's column update (RCGP_SPLIT)
   hipEvent_t ev_inv = nullptr;       // last overlapped L^-1 kernel

@@ -657,12 +657,15 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
   // late: the diagonal kernel only factors (k_diag2<1>); the 128x128 inverse and w_j follow on the column-work stream (k_diag2<2>, ahead
   // of the panel solve that needs them) and the chain's tile is solved by substitution (k_prep1s)
   const bool late = (h->prep_split == 3) && h->diag_variant != 1;
+  // t2p: the panel solve T2(j) waits for P(j)'s solved tile instead of D(j), so that D(j) carries no completion event (a dispatch that
+  // carries one delays its successor on the stream by ~5 us: kernel trace)
+  const bool t2p = h->t2_after_p && !late;
   for (int64_t j = 0; j < Np; j += 128) {
     const int64_t below = Np - (j + 128);
     hipEvent_t eD = nullptr, eP, eG;
     if ((below > 0 || late) && (rc = next_event(h, &eD))) return rc;
     h->launch = C;
-    if (ext) h->launch_stop = eD;
+    if (ext && !t2p) h->launch_stop = eD;
     if ((rc = rc_launch_diag(h, j, late ? 1 : 0)) || (rc = flush_stop(h))) return rc;
     if (late) {
       if (!ext) RC_HIP(hipEventRecord(eD, C));
@@ -678,7 +681,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     double* P = h->A + (j + 128) * Np + j;                       // rows below the diagonal block, 128 columns
     const double* inv = h->invdiag + (j / 128) * 128 * 128;
     if ((rc = next_event(h, &eP)) || (rc = next_event(h, &eG))) return rc;
-    if (!late) {
+    if (!late && !t2p) {
       if (!ext) RC_HIP(hipEventRecord(eD, C));
       RC_HIP(hipStreamWaitEvent(B, eD, 0));
     }
@@ -694,6 +697,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     if (rc || (rc = flush_stop(h))) return rc;
     if (!ext) RC_HIP(hipEventRecord(eP, C));
     h->launch = B;
+    if (t2p) RC_HIP(hipStreamWaitEvent(B, eP, 0));
     hipEvent_t ePanel = eG;                                       // everything of this step on B (and B2) done
     if (below > 128 && h->chain_split) {
       // G(j) in two kernels: the two block columns the NEXT chain step reads (near, on B; P(j+1) waits for it alone) and the

@@ -1,8 +1,8 @@
-"""Kernel parameter store (reference gpr/kernels.py:30-180). A Kernel is a Model whose Data are the kernel variance,
-(1,L) for independent outputs, and the lengthscales, (L,M) anisotropic or (L,1) isotropic. In the reference
-``implementation`` builds GPflow kernel objects; here it yields plain per-output parameter records that the HIP-backed GP
-pushes to the device with ``rcgp_set_hyper`` -- the kernel arithmetic itself lives in csrc/gram.hip. An (L,L) variance is the
-covariant kernel of ``romcomma.gpf.kernels.RBF``: one record for all outputs, pushed with ``rcgp_set_hyper_mo``.
+"""Kernel parameter store (contract: reference gpr/kernels.py:30-180). A Kernel is a Model whose parameters are the kernel
+variance -- (1,L) for independent outputs, (L,L) for the covariant kernel of ``romcomma.gpf.kernels.RBF`` -- and the lengthscales,
+(L,M) anisotropic or (L,1) isotropic. Where the reference's ``implementation`` builds GPflow kernel objects, this one yields plain
+per-output parameter records that the HIP-backed GP pushes to the device (``rcgp_set_hyper`` / ``rcgp_set_hyper_mo``): the kernel
+arithmetic itself lives in csrc/gram.hip.
 """
 from __future__ import annotations
 
@@ -14,58 +14,56 @@ import numpy as np
 
 from romcomma_amd.base.classes import Data, Model
 
+VARIANCE_DEFAULT, LENGTHSCALE_DEFAULT = 2.0, 5.0        # gpr/kernels.py:49-50
+
+
+def _subclass_where(base: type, test, complaint: str) -> type:
+    for candidate in base.__subclasses__():
+        if test(candidate):
+            return candidate
+    raise TypeError(complaint)
+
 
 class Kernel(Model):
-    """Abstract kernel: the code contract with the GPR interface."""
+    """The code contract between a kernel and the GPR interface."""
 
     class Data(Data):
         class NamedTuple(NamedTuple):
-            variance: Any = np.atleast_2d(2.0)          # reference default, gpr/kernels.py:49
-            lengthscales: Any = np.atleast_2d(5.0)      # reference default, gpr/kernels.py:50
+            variance: Any = np.atleast_2d(VARIANCE_DEFAULT)
+            lengthscales: Any = np.atleast_2d(LENGTHSCALE_DEFAULT)
+
+    VARIANCE_FLOOR: float = 1.0005E-6                   # gpr/kernels.py:176
 
     @classmethod
     @property
     def META(cls) -> Dict[str, Any]:
+        """Which hyper-parameters train by default: variance and per-output lengthscales yes, the covariant parts no."""
         return {'variance': True, 'covariance': False, 'lengthscales': {'variant': True, 'covariant': False}}
-
-    VARIANCE_FLOOR: float = 1.0005E-6                   # gpr/kernels.py:176
 
     def __init__(self, folder: Path | str, read_data: bool = False, **kwargs: Any):
         super().__init__(folder, read_data, **kwargs)
-        variance_shape = self._data.frames.variance.df.shape
-        self._L, self._M = variance_shape[1], self._data.frames.lengthscales.df.shape[1]
+        frames = self._data.frames
+        stored_variance_shape = frames.variance.df.shape
+        self._L = stored_variance_shape[1]
+        self._M = frames.lengthscales.df.shape[1]
         self._trainable = self.META
-        self.broadcast_parameters(variance_shape, self._M)
+        self.broadcast_parameters(stored_variance_shape, self._M)
 
-    def calibrate(self, **kwargs: Any) -> Dict[str, Any]:
-        """Records which hyper-parameters are trainable; returns the merged options (gpr/kernels.py:59-70)."""
-        self._trainable = self.META | kwargs
-        return self._trainable
-
-    @property
-    def trainable(self) -> Dict[str, Any]:
-        return self._trainable
-
+    # -- identity: '<module>.<class>' is what ``<gp>/kernel.csv`` stores (gpr/kernels.py:72-76)
     @classmethod
     @property
     def TYPE_IDENTIFIER(cls) -> str:
-        """``<module>.<class>``, e.g. 'kernels.RBF': the string stored in ``<gp>/kernel.csv`` (gpr/kernels.py:72-76)."""
-        return cls.__module__.split('.')[-1] + '.' + cls.__name__
+        return f"{cls.__module__.rsplit('.', 1)[-1]}.{cls.__name__}"
 
     @classmethod
     def TypeFromIdentifier(cls, TypeIdentifier: str) -> Type['Kernel']:
-        for kernel_type in cls.__subclasses__():
-            if kernel_type.TYPE_IDENTIFIER == TypeIdentifier:
-                return kernel_type
-        raise TypeError('Kernel.TypeIdentifier() of unrecognizable type.')
+        return _subclass_where(cls, lambda k: k.TYPE_IDENTIFIER == TypeIdentifier, 'Kernel.TypeIdentifier() of unrecognizable type.')
 
     @classmethod
     def TypeFromParameters(cls, parameters: Data) -> Type['Kernel']:
-        for kernel_type in cls.__subclasses__():
-            if isinstance(parameters, kernel_type.Data):
-                return kernel_type
-        raise TypeError('Kernel Data array of unrecognizable type.')
+        return _subclass_where(cls, lambda k: isinstance(parameters, k.Data), 'Kernel Data array of unrecognizable type.')
 
+    # -- shape
     @property
     def L(self) -> int:
         return self._L
@@ -79,21 +77,33 @@ class Kernel(Model):
         return self._data.frames.variance.df.shape[0] > 1
 
     def broadcast_parameters(self, variance_shape: Tuple[int, int], M: int) -> 'Kernel':
-        """Broadcast to more outputs / input dimensions; shrinking raises IndexError (gpr/kernels.py:121-139)."""
-        if tuple(variance_shape) != self._data.frames.variance.df.shape:
-            self._data.frames.variance.broadcast_value(target_shape=tuple(variance_shape), is_diagonal=True)
+        """To more outputs / input dimensions; what is already the right shape is left alone, shrinking raises IndexError (in the
+        frame). The per-output records are rebuilt."""
+        frames = self._data.frames
+        variance_shape = tuple(variance_shape)
+        if frames.variance.df.shape != variance_shape:
+            frames.variance.broadcast_value(target_shape=variance_shape, is_diagonal=True)
             self._L = variance_shape[1]
-        if (self._L, M) != self._data.frames.lengthscales.df.shape:
-            self._data.frames.lengthscales.broadcast_value(target_shape=(self._L, M), is_diagonal=False)
+        if frames.lengthscales.df.shape != (self._L, M):
+            frames.lengthscales.broadcast_value(target_shape=(self._L, M), is_diagonal=False)
             self._M = M
         self._implementation = None
         self._implementation = self.implementation
         return self
 
+    # -- training flags (gf.set_trainable in the reference, gpr/kernels.py:59-70)
+    def calibrate(self, **kwargs: Any) -> Dict[str, Any]:
+        self._trainable = {**self.META, **kwargs}
+        return self._trainable
+
+    @property
+    def trainable(self) -> Dict[str, Any]:
+        return self._trainable
+
     @property
     @abstractmethod
     def implementation(self) -> Tuple[Any, ...]:
-        """One record per independent output."""
+        """One record per independent output (one for all outputs of a covariant kernel)."""
 
 
 class RBF(Kernel):
@@ -101,15 +111,15 @@ class RBF(Kernel):
 
     @property
     def implementation(self) -> Tuple[Dict[str, Any], ...]:
-        variance = self._data.frames.variance.np
-        lengthscales = self._data.frames.lengthscales.np
-        if self._implementation is None:
-            if variance.shape[0] != 1:
-                # one multi-output kernel (gpr/kernels.py:179): (L,L) variance, (L,M) or (L,1) lengthscales (gpf/kernels.py:106-127)
-                self._implementation = ({'variance': np.asarray(variance, dtype=float).copy(),
-                                         'lengthscales': np.asarray(lengthscales, dtype=float).copy()},)
-                return self._implementation
-            self._implementation = tuple({'variance': max(float(variance[0, l]), self.VARIANCE_FLOOR),
-                                          'lengthscales': np.asarray(lengthscales[l], dtype=float).copy()}
-                                         for l in range(variance.shape[1]))
-        return self._implementation
+        if self._implementation is not None:
+            return self._implementation
+        variance = np.asarray(self._data.frames.variance.np, dtype=float)
+        lengthscales = np.asarray(self._data.frames.lengthscales.np, dtype=float)
+        if variance.shape[0] > 1:
+            # ONE multi-output kernel (gpr/kernels.py:179): (L,L) variance, (L,M) or (L,1) lengthscales (gpf/kernels.py:106-127)
+            records = ({'variance': variance.copy(), 'lengthscales': lengthscales.copy()},)
+        else:
+            records = tuple({'variance': max(float(v), self.VARIANCE_FLOOR), 'lengthscales': row.copy()}
+                            for v, row in zip(variance[0], lengthscales))
+        self._implementation = records
+        return records
