@@ -139,6 +139,9 @@ def main():
     ap.add_argument('--profile-every', type=int, default=6,
                     help='within a profiled step, the evaluations whose launches carry HIP events: every n-th one (1 = all)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group even for one rank (exercises RCCL on a 1-GPU box)')
+    ap.add_argument('--backend', choices=('nccl', 'gloo'), default=None,
+                    help='torch.distributed backend (default: nccl = RCCL when a GPU is visible). gloo lets several ranks share ONE GPU: the way the '
+                         'N > 1 path is rehearsed on a one-GPU box (RCCL refuses two ranks on one device)')
     args = ap.parse_args()
 
     from romcomma_amd import _lib, dist
@@ -147,10 +150,11 @@ def main():
 
     rank, world, local_rank = dist.env_rank_world()
     if world > 1 or args.force_dist:
-        dist.init_process_group()
+        dist.init_process_group(args.backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     if _lib.device_count() <= 0:
         raise SystemExit('bench.py needs a GPU: librcgp has no CPU fallback')
+    local_rank = local_rank % _lib.device_count()         # one rank per GPU on a full node; ranks share the device in the gloo rehearsal
 
     N, M = args.n, args.m
     K_folds = max(8, world)                          # folds of a K-fold split of one seeded dataset: every fold trains on N rows

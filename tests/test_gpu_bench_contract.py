@@ -53,3 +53,24 @@ def test_bench_under_torch_distributed_run_exercises_rccl(gpu):
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['value'] > 0 and 'cpu_baseline' not in d
+
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(gpu):
+    """The N = 2 path of bench.py end to end -- torch.distributed.run with two ranks, fold (r + step) mod 8 per rank, barrier, MAX over
+    ranks, the gather of both ranks' rows, value = 2 N steps / time -- rehearsed with both ranks on the one GPU of this box over gloo
+    (on an 8-GPU node the driver launches the same command with the default backend: RCCL over xGMI, one rank per GPU)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--rows', '1024', '--dims', '3', '--backend', 'gloo']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and 'cpu_baseline' not in d
+    assert d['value'] == pytest.approx(2 * 1024 * 2 / (d['ms_per_step'] * 2e-3), rel=1e-9)
+    assert 'x2' in d['config']['parallelism']
