@@ -90,6 +90,8 @@ static void free_all(rcgp_handle_s* h) {
   h->info = nullptr;                                       // (inside scal)
   h->FS_d = nullptr;                                       // (inside ell_d's allocation)
   if (h->pin) { (void)hipHostFree(h->pin); h->pin = nullptr; }
+  if (h->sig_flag) { (void)hipFree(h->sig_flag); h->sig_flag = nullptr; }
+  if (h->heavy_ctr) { (void)hipFree(h->heavy_ctr); h->heavy_ctr = nullptr; }
   if (h->ev_hyper) { (void)hipEventDestroy(h->ev_hyper); h->ev_hyper = nullptr; }
   for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
   h->prof_events.clear();
@@ -212,6 +214,20 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   if (const char* e = getenv("RCGP_SHORTK")) h->short_k = (e[0] != '0');
   if (const char* e = getenv("RCGP_GRAD_ORDER")) h->grad_order = atoi(e);
   if (const char* e = getenv("RCGP_T2WAIT")) h->t2_after_p = (e[0] != '0');
+  if (const char* e = getenv("RCGP_HEAVY")) h->heavy_mode = atoi(e);
+  if (const char* e = getenv("RCGP_HEAVY_RESERVE")) h->heavy_reserve_mod = atoi(e);
+  if (h->heavy_mode) {
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess || !can ||
+        hipExtMallocWithFlags((void**)&h->sig_flag, sizeof(uint64_t), hipMallocSignalMemory) != hipSuccess) {
+      (void)hipGetLastError();
+      h->sig_flag = nullptr;
+      h->heavy_mode = 0;                               // no stream wait-value on this device: window pieces + bulk kernels
+    } else {
+      RC_HIP(hipMemsetAsync(h->sig_flag, 0, sizeof(uint64_t), h->stream));
+      RC_HIP(hipMalloc(&h->heavy_ctr, 2 * RC_MAX_PANELS * sizeof(int)));
+    }
+  }
   if (const char* e = getenv("RCGP_INV_EVERY")) {
     const int x = atoi(e);
     if (x >= 1) h->inv_every = x;

@@ -15,6 +15,7 @@
 #define RC_RESERVE_CUS_DEFAULT 0   // CUs the bulk-update stream leaves to the panel chain (RCGP_RESERVE_CUS); 0 = no CU mask
 #define RC_SCAL_ELEMS 256      // h->scal: [0,2) LML sums, [8, 8+M+2) gradient sums, [RC_SCAL_INFO] the Cholesky status word
 #define RC_SCAL_INFO 128
+#define RC_MAX_PANELS 512        // outer panels of one factorisation the heavy-update counters provide for
 #define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -47,6 +48,11 @@ struct rcgp_handle_s {
   bool prep_attr_set = false, prep_s_attr_set = false;
   int grad_order = 0;                // k_grad tile order: 0 = heavy-first rows; 1 = 8 x 8 super-blocks per XCD with a common k start (measured: HBM reads -7 %,
                                      // time +13 % -- prefetching workgroups drift apart) (RCGP_GRAD_ORDER)
+  int heavy_mode = 1;                // 1: one persistent k_heavy_update per finished panel instead of window pieces + bulk kernel (RCGP_HEAVY)
+  int heavy_reserve_mod = 2;         // its workgroups stay off cu 4 of every heavy_reserve_mod-th shader engine (1: 32 CUs, 2: 16, 4: 8; 0: none) (RCGP_HEAVY_RESERVE)
+  uint64_t* sig_flag = nullptr;      // 8 bytes of signal memory: progress word of the heavy update (hipStreamWaitValue64)
+  uint64_t sig_value = 0;            // last value handed out (monotonic over the life of the handle)
+  int* heavy_ctr = nullptr;          // device: two counters per outer panel, zeroed at the start of every factorisation
   bool t2_after_p = false;           // the panel solve waits for the chain's solved tile instead of the diagonal kernel (RCGP_T2WAIT)
   bool short_k = true;               // K = 128 kernels of the panel chain request all their operand slabs up front (RCGP_SHORTK)
   bool chain_split = true;           // near / far split of the chain's column update (RCGP_SPLIT)
@@ -192,6 +198,9 @@ int rc_launch_cross_gram(rcgp_handle_s* h, int64_t n, int64_t np, int out = 0); 
 // ---- gemm.hip (all matrices row-major, dims multiples of 128)
 // C[i][j] -= sum_k P[i][k] P[j][k]   lower tiles of an n x n matrix, K = kk
 int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk);
+// the same as one persistent launch that stays off the reserved CUs and publishes the completion of its first n_first_cols columns
+int rc_launch_heavy_update(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk, int64_t n_first_cols,
+                           int* ctr, unsigned long long value);
 // C (m x n) -= Arows (m x kk) * Brows (n x kk)^T ; tiles strictly above the diagonal of C (given the global row/col offsets) skipped
 int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0);

@@ -13,6 +13,7 @@
 // C/D lane l register r holds C[row=(l>>4)+4r][col=l&15].
 #include "common.h"
 #include "rc_math.h"
+#include <algorithm>
 
 #ifndef LDK
 #define LDK 17          // row stride (doubles) of a KC=true LDS slab: [128][17]. ODD: hipcc fuses the fragment reads into
@@ -83,7 +84,9 @@ __device__ __forceinline__ double frag_read(const double* lds, int row, int k) {
 }
 
 // acc (+/-)= A(i, k0:k1) * B(j, k0:k1)^T for the 128x128 tile (i from a0, j from b0). k0,k1 multiples of 16, k1 > k0.
-// NEG = true subtracts the product (the A fragment is negated), so that an update kernel can start from acc = C.
+// NEG = true subtracts the product, so that an update kernel can start from acc = C: the A operand is negated BY THE MFMA ITSELF (the
+// last builtin argument, BLGP, is the NEG field of the fp64 MFMAs on gfx940+: 1 = neg:[1,0,0]). A v_xor per A fragment instead -- 16 VALU
+// instructions per slab and wave -- cost the update kernels 5-7 % (tools/gemm_rate.hip: 71.3 -> 67.5 TFLOP/s at K = 1024 on idle operands).
 template <bool AKC, bool BKC, int WN, bool NEG = false>
 __device__ __forceinline__ void gemm_mainloop(const double* __restrict__ A, int64_t lda, int64_t a0, const double* __restrict__ B,
                                               int64_t ldb, int64_t b0, int64_t k0, int64_t k1, v4d (&acc)[4][Geo<WN>::NI], double* lds) {
@@ -110,16 +113,13 @@ __device__ __forceinline__ void gemm_mainloop(const double* __restrict__ A, int6
     for (int s = 0; s < 4; ++s) {
       double af[4], bf[NI];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const double v = frag_read<AKC>(la, wr + 16 * x + fr, 4 * s + fq);
-        af[x] = NEG ? -v : v;
-      }
+      for (int x = 0; x < 4; ++x) af[x] = frag_read<AKC>(la, wr + 16 * x + fr, 4 * s + fq);
 #pragma unroll
       for (int x = 0; x < NI; ++x) bf[x] = frag_read<BKC>(lb, wc + 16 * x + fr, 4 * s + fq);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, NEG ? 1 : 0);
     }
     double* na = lds + ((kt + 1) & 1) * 2 * SLAB;
     slab_store<AKC, WN>(na, ra);
@@ -164,16 +164,13 @@ __device__ __forceinline__ void gemm_mainloop_pre(const double* __restrict__ A, 
     for (int s = 0; s < 4; ++s) {
       double af[4], bf[NI];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const double v = frag_read<AKC>(la, wr + 16 * x + fr, 4 * s + fq);
-        af[x] = NEG ? -v : v;
-      }
+      for (int x = 0; x < 4; ++x) af[x] = frag_read<AKC>(la, wr + 16 * x + fr, 4 * s + fq);
 #pragma unroll
       for (int x = 0; x < NI; ++x) bf[x] = frag_read<BKC>(lb, wc + 16 * x + fr, 4 * s + fq);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, NEG ? 1 : 0);
     }
     if (kt + 1 < NK) {
       double* na = lds + ((kt + 1) & 1) * 2 * SLAB;
@@ -306,6 +303,90 @@ int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double*
   RcProfScope ps(h, RC_K_GEMM, (double)n * (double)(n + 128) * (double)kk, true);   // 2*kk flops per lower-tile element
   const dim3 grid((unsigned)(T * (T + 1) / 2)), block(128 * RC_WN);
   RC_LAUNCH((k_syrk_lower<RC_WN, 3>), grid, block, 0, C, ldc, P, ldp, (int)kk);
+  RC_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_heavy_update: the WHOLE K = NB trailing update of one finished outer panel (what the window pieces and the bulk k_syrk_lower do
+// between them) as ONE persistent launch that leaves room for the panel chain. A kernel trace of the C2 factorisation shows why:
+// with a window piece and a bulk kernel in flight every CU holds two long-running GEMM workgroups at all times, and the chain's
+// whole-CU kernels (k_diag2: 150 KB of LDS, k_prep1: 138 KB x 8) wait MILLISECONDS for a CU on which both slots happen to be free
+// together (k_prep1 2.5 ms instead of 7 us at the start of panel 2): bulk update and chain run one after the other, not side by side.
+//   * 256 workgroups, ONE per CU (84 KB of LDS: two do not fit a CU, one fits beside a 74 KB column-work workgroup), looping over the
+//     lower tiles of the trailing matrix through an atomic counter; tiles in column-major order, so the next panel's columns come first;
+//   * workgroups that find themselves on a RESERVED CU (HW_ID.cu_id == 4 on every reserve_mod-th shader engine: one CU per SE, up to
+//     32) return at once: the kernel never occupies those CUs, the chain's whole-CU kernels find them (HIP has no CU affinity for
+//     kernels; CU-masked queues put this runtime in a slower regime);
+//   * when the first n_first tiles (the first column panel = what the window piece did) are complete, the last finisher publishes
+//     `value` in `flag` (signal memory): the chain's streams wait for it with hipStreamWaitValue64 (3 us hand-over) -- a kernel
+//     boundary would only come at the end of the whole update.
+// No workgroup ever waits for another: nothing can deadlock. ctr[0] hands out tiles, ctr[1] counts finished first-panel tiles.
+// ---------------------------------------------------------------------------------------------------------------------
+#define RC_HEAVY_LDS_PAD 1284           // doubles on top of the operand ring: 84 000 B per workgroup
+
+__device__ __forceinline__ bool rc_on_reserved_cu(int reserve_mod) {
+  if (reserve_mod <= 0) return false;
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);       // HW_ID
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;  // XCC_ID
+  const int cu = (hw >> 8) & 15, se = (hw >> 13) & 7;
+  return cu == 4 && ((int)(xcc * 4 + se) % reserve_mod) == 0;
+}
+
+template <int WN>
+__global__ void RC_BOUNDS(WN) k_heavy_update(double* __restrict__ C, int64_t ldc, const double* __restrict__ P, int64_t ldp, int kk,
+                                                          int T, int ntiles, int n_first, int* __restrict__ ctr,
+                                                          unsigned long long* __restrict__ flag, unsigned long long value, int reserve_mod) {
+  // (the padding that keeps a second workgroup of this kernel off the CU is DYNAMIC shared memory, requested at launch: with it in the
+  // static size the compiler sees an LDS-bound occupancy of 2 waves per SIMD and spends 169 registers, which would keep the
+  // column-work workgroup off the CU as well)
+  __shared__ double lds[GEMM_LDS];
+  __shared__ int s_tile;
+  if (rc_on_reserved_cu(reserve_mod)) return;
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(&ctr[0], 1);
+    __syncthreads();
+    const int id = __builtin_amdgcn_readfirstlane(s_tile);      // workgroup-uniform: scalar registers, not 64 copies
+    if (id >= ntiles) break;
+    // column-major lower triangle: column tj holds the T - tj tiles ti = tj .. T-1; cum(tj) = tj T - tj (tj - 1) / 2
+    const double b = 2.0 * T + 1.0;
+    int tj = (int)((b - sqrt(b * b - 8.0 * (double)id)) * 0.5);
+    if (tj < 0) tj = 0;
+    if (tj > T - 1) tj = T - 1;
+    while (tj > 0 && (int64_t)tj * T - (int64_t)tj * (tj - 1) / 2 > id) --tj;
+    while ((int64_t)(tj + 1) * T - (int64_t)(tj + 1) * tj / 2 <= id) ++tj;
+    tj = __builtin_amdgcn_readfirstlane(tj);
+    const int ti = tj + (int)(id - ((int64_t)tj * T - (int64_t)tj * (tj - 1) / 2));
+    v4d acc[4][Geo<WN>::NI];
+    double* Ct = C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128;
+    acc_load_staged<WN>(acc, Ct, ldc, lds);
+    gemm_mainloop<true, true, WN, true>(P, ldp, (int64_t)ti * 128, P, ldp, (int64_t)tj * 128, 0, kk, acc, lds);
+    acc_store_staged<WN>(acc, Ct, ldc, lds);
+    if (id < n_first) {                              // a tile the chain is waiting for: publish it before it is counted
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0 && atomicAdd(&ctr[1], 1) == n_first - 1) {
+        __threadfence();
+        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    __syncthreads();                                 // s_tile is rewritten at the top
+  }
+}
+
+// K = kk update of the lower tiles of the n x n matrix at C with the panel P (n x kk), n_first_cols = columns (a multiple of 128) whose
+// completion is published in h->sig_flag as `value`; ctr = two zeroed ints.
+int rc_launch_heavy_update(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk, int64_t n_first_cols,
+                           int* ctr, unsigned long long value) {
+  const int T = (int)(n / 128);
+  if (T <= 0) return 0;
+  const int ntiles = (int)((int64_t)T * (T + 1) / 2);
+  const int cf = (int)std::min<int64_t>(n_first_cols / 128, T);
+  const int n_first = (int)((int64_t)cf * T - (int64_t)cf * (cf - 1) / 2);
+  RcProfScope ps(h, RC_K_GEMM, (double)n * (double)(n + 128) * (double)kk, true);
+  const int grid = ntiles < 256 ? ntiles : 256;
+  RC_LAUNCH((k_heavy_update<RC_WN>), dim3((unsigned)grid), dim3(128 * RC_WN), RC_HEAVY_LDS_PAD * sizeof(double), C, ldc, P, ldp, (int)kk, T, ntiles, n_first, ctr,
+            (unsigned long long*)h->sig_flag, value, h->heavy_reserve_mod);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -571,11 +652,11 @@ __global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, do
       double av[4], bv[4];
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
-        av[s2] = -La[(16 * ti + fr) * LP + 16 * kt + 4 * s2 + fq];
+        av[s2] = La[(16 * ti + fr) * LP + 16 * kt + 4 * s2 + fq];
         bv[s2] = Lb[(16 * tj + fr) * LP + 16 * kt + 4 * s2 + fq];
       }
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
+      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 1);     // neg:[1,0,0]
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) Dt[(int64_t)(fq + 4 * q) * ld + fr] = acc[q];
@@ -637,9 +718,9 @@ __global__ void __launch_bounds__(256) k_prep1s(double* T, int64_t ld, const dou
     for (int k = 0; k < c; ++k) {
       double av[4];
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) av[s2] = -Ls[(16 * c + fr) * LP + 16 * k + 4 * s2 + fq];   // -L_ck[i = fr][4 s + fq]
+      for (int s2 = 0; s2 < 4; ++s2) av[s2] = Ls[(16 * c + fr) * LP + 16 * k + 4 * s2 + fq];    // L_ck[i = fr][4 s + fq], negated by the MFMA
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Y[k][s2], acc, 0, 0, 0);
+      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Y[k][s2], acc, 0, 0, 1);
     }
     double xv[4];
 #pragma unroll

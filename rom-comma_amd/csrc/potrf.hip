@@ -416,9 +416,9 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int k = 4 * s + fq;
-        const double av = -S[(16 * rb + fr) * LS + 16 * cp + k];         // -L_{rb,cp}[i][k]
+        const double av = S[(16 * rb + fr) * LS + 16 * cp + k];          // L_{rb,cp}[i][k], negated by the MFMA (neg:[1,0,0])
         const double bv = S[(16 * cb + fr) * LS + 16 * cp + k];          // B[k][j] = L_{cb,cp}[j][k]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 1);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) S[(16 * rb + fq + 4 * q) * LS + 16 * cb + fr] = acc[q];
@@ -523,11 +523,11 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
         const int astep = (kb == rb) ? 4 : 4 * LS;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          av[s] = -asrc[s * astep];
+          av[s] = asrc[s * astep];                                                      // (negated by the MFMA)
           bv[s] = S[(16 * cb + fr) * LS + 16 * kb + 4 * s + fq];                        // T_{kb,cb}[k][j] at S[j][k]
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 1);
       }
       tacc[n] = acc;
     }
@@ -653,6 +653,15 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
   RC_HIP(hipStreamWaitEvent(B2, e0, 0));
   bool near_waited = false, far_waited = false;                  // this panel's wait for the previous panel's window piece
   int64_t u0_prev = 0;                                           // first column of that piece
+  // heavy: pieces + bulk of a finished panel are ONE persistent k_heavy_update on U2; "the window piece is done" is then a value in
+  // the handle's signal word, waited for with hipStreamWaitValue64, not an event
+  const bool heavy = h->heavy_mode && h->sig_flag && h->heavy_ctr;
+  uint64_t hv_prev = 0;
+  bool have_win = false;                                         // a previous panel's first column panel has to be waited for
+  auto wait_window = [&](hipStream_t st) -> hipError_t {
+    if (heavy) return hipStreamWaitValue64(st, h->sig_flag, hv_prev, hipStreamWaitValueGte, 0xffffffffffffffffull);
+    return hipStreamWaitEvent(st, eU1_prev, 0);
+  };
   const bool ext = h->ext_events && !h->profiling;              // (the profiling bracket records its own events around a launch)
   // late: the diagonal kernel only factors (k_diag2<1>); the 128x128 inverse and w_j follow on the column-work stream (k_diag2<2>, ahead
   // of the panel solve that needs them) and the chain's tile is solved by substitution (k_prep1s)
@@ -686,7 +695,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
       RC_HIP(hipStreamWaitEvent(B, eD, 0));
     }
     if (eG_prev) RC_HIP(hipStreamWaitEvent(C, eG_prev, 0));
-    if (first_of_panel && eU1_prev && h->chain_ext < 2) RC_HIP(hipStreamWaitEvent(C, eU1_prev, 0));   // P touches column j + 128 >= u0
+    if (first_of_panel && have_win && h->chain_ext < 2) RC_HIP(wait_window(C));   // P touches column j + 128 >= u0
     if (ext) h->launch_stop = eP;                                 // (with the split: taken by k_prep1 -- the column work needs the solved tile only)
     if (late)
       rc = rc_launch_prep_subst(h, P, h->A + (j + 128) * Np + (j + 128), Np, h->A + j * Np + j, inv);
@@ -711,7 +720,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
       const int64_t c0 = j + 128, nend = (c0 + 256 < cend) ? c0 + 256 : cend;
       RC_HIP(hipStreamWaitEvent(B, eP, 0));
       if (eFar_prev) RC_HIP(hipStreamWaitEvent(B, eFar_prev, 0));
-      if (eU1_prev && !near_waited && nend > u0_prev) { RC_HIP(hipStreamWaitEvent(B, eU1_prev, 0)); near_waited = true; }
+      if (have_win && !near_waited && nend > u0_prev) { RC_HIP(wait_window(B)); near_waited = true; }
       if (ext) h->launch_stop = eG;
       if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + c0, Np, P + 128 * Np, Np, P, Np, below - 128, nend - c0, 128, j + 256, c0)) ||
           (rc = flush_stop(h)))
@@ -720,7 +729,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
       if (cend > nend) {
         if ((rc = next_event(h, &eFar))) return rc;
         RC_HIP(hipStreamWaitEvent(B2, eT2, 0));
-        if (eU1_prev && !far_waited && cend > u0_prev) { RC_HIP(hipStreamWaitEvent(B2, eU1_prev, 0)); far_waited = true; }
+        if (have_win && !far_waited && cend > u0_prev) { RC_HIP(wait_window(B2)); far_waited = true; }
         h->launch = B2;
         if (ext) h->launch_stop = eFar;
         if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + nend, Np, P + 128 * Np, Np, P + (nend - c0) * Np, Np, below - 128, cend - nend,
@@ -737,7 +746,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
       }
     } else if (below > 128) {
       if ((rc = rc_launch_trsm_panel(h, P + 128 * Np, Np, inv, below - 128, h->w + j + 256, h->w + j))) return rc;
-      if (first_of_panel && eU1_prev) RC_HIP(hipStreamWaitEvent(B, eU1_prev, 0));
+      if (first_of_panel && have_win) RC_HIP(wait_window(B));
       RC_HIP(hipStreamWaitEvent(B, eP, 0));
       if (ext) h->launch_stop = eG;
       if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + (j + 128), Np, P + 128 * Np, Np, P, Np, below - 128, cend - (j + 128), 128,
@@ -759,9 +768,26 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
       // them in one bulk kernel on the bulk stream. A column panel leaves the bulk kernel's domain one panel before the
       // chain reaches it with depth 1, `depth` panels before with a deeper window: the chain may run that far ahead of the bulk.
       eU1_prev = nullptr;
+      have_win = false;
       const int depth = h->chain_depth;
       const double* Lp0 = h->A + (pend - NB);                     // column offset of the finished panel
       hipEvent_t eR_new = nullptr;
+      if (heavy) {
+        const int64_t u0 = pend + EXT;
+        const int64_t pidx = pend / NB - 1;
+        if (u0 < Np && pidx < RC_MAX_PANELS) {
+          if ((rc = next_event(h, &eR_new))) return rc;
+          RC_HIP(hipStreamWaitEvent(U2, eG, 0));
+          h->launch = U2;
+          if (ext) h->launch_stop = eR_new;
+          hv_prev = ++h->sig_value;
+          if ((rc = rc_launch_heavy_update(h, h->A + u0 * Np + u0, Np, Lp0 + u0 * Np, Np, Np - u0, NB, NB, h->heavy_ctr + 2 * pidx, hv_prev)) ||
+              (rc = flush_stop(h)))
+            return rc;
+          if (!ext) RC_HIP(hipEventRecord(eR_new, U2));
+          have_win = true;
+        }
+      } else {
       for (int q = 0; q <= depth; ++q) {
         const int64_t u0 = pend + EXT + (int64_t)q * NB;
         if (u0 >= Np) break;
@@ -781,6 +807,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
           if (q == 0) {
             if (!ext) RC_HIP(hipEventRecord(eU1, U1));
             eU1_prev = eU1;
+            have_win = true;
           }
         } else {                                                  // bulk: everything from u0 on
           if ((rc = next_event(h, &eR_new))) return rc;
@@ -790,6 +817,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
           if ((rc = rc_launch_syrk_lower(h, h->A + u0 * Np + u0, Np, Lp0 + u0 * Np, Np, Np - u0, NB)) || (rc = flush_stop(h))) return rc;
           if (!ext) RC_HIP(hipEventRecord(eR_new, U2));
         }
+      }
       }
       eU2_prev = eR_new;
       if (overlap_inverse && (pend / NB) % h->inv_every == 0) {   // rows < pend of L are final: feed the L^-1 kernels that only need those
@@ -826,6 +854,7 @@ int rc_potrf(rcgp_handle_s* h) {
   h->prof_pending = -1;
   RC_HIP(hipMemcpyAsync(h->w, h->y, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   RC_HIP(hipMemsetAsync(h->info, 0, sizeof(int), h->stream));
+  if (h->heavy_ctr) RC_HIP(hipMemsetAsync(h->heavy_ctr, 0, 2 * RC_MAX_PANELS * sizeof(int), h->stream));   // tile / completion counters of the heavy updates
   const int64_t npanels = (Np + NB - 1) / NB;
   const bool la = h->lookahead && Np >= 4 * 128;                   // (the multi-stream schedule needs no minimum number of panels)
   const bool inv = la && h->overlap_inverse;                      // feed L^-1 kernels into the idle CUs of the chain-bound tail
