@@ -91,6 +91,8 @@ static void free_all(rcgp_handle_s* h) {
   h->FS_d = nullptr;                                       // (inside ell_d's allocation)
   if (h->pin) { (void)hipHostFree(h->pin); h->pin = nullptr; }
   if (h->sig_flag) { (void)hipFree(h->sig_flag); h->sig_flag = nullptr; }
+  if (h->sig_ready) { (void)hipFree(h->sig_ready); h->sig_ready = nullptr; }
+  if (h->sig_done) { (void)hipFree(h->sig_done); h->sig_done = nullptr; }
   if (h->heavy_ctr) { (void)hipFree(h->heavy_ctr); h->heavy_ctr = nullptr; }
   if (h->ev_hyper) { (void)hipEventDestroy(h->ev_hyper); h->ev_hyper = nullptr; }
   for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
@@ -214,7 +216,21 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   if (const char* e = getenv("RCGP_SHORTK")) h->short_k = (e[0] != '0');
   if (const char* e = getenv("RCGP_GRAD_ORDER")) h->grad_order = atoi(e);
   if (const char* e = getenv("RCGP_T2WAIT")) h->t2_after_p = (e[0] != '0');
+  if (const char* e = getenv("RCGP_BULK_AFTER_PIECE")) h->bulk_after_piece = (e[0] != '0');
   if (const char* e = getenv("RCGP_HEAVY")) h->heavy_mode = atoi(e);
+  if (const char* e = getenv("RCGP_DLOOP")) h->dloop = atoi(e);
+  if (h->dloop) {
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess || !can ||
+        hipExtMallocWithFlags((void**)&h->sig_ready, sizeof(uint64_t), hipMallocSignalMemory) != hipSuccess ||
+        hipExtMallocWithFlags((void**)&h->sig_done, sizeof(uint64_t), hipMallocSignalMemory) != hipSuccess) {
+      (void)hipGetLastError();
+      h->dloop = 0;
+    } else {
+      RC_HIP(hipMemsetAsync(h->sig_ready, 0, sizeof(uint64_t), h->stream));
+      RC_HIP(hipMemsetAsync(h->sig_done, 0, sizeof(uint64_t), h->stream));
+    }
+  }
   if (const char* e = getenv("RCGP_HEAVY_RESERVE")) h->heavy_reserve_mod = atoi(e);
   if (h->heavy_mode) {
     int can = 0;

@@ -48,11 +48,18 @@ struct rcgp_handle_s {
   bool prep_attr_set = false, prep_s_attr_set = false;
   int grad_order = 0;                // k_grad tile order: 0 = heavy-first rows; 1 = 8 x 8 super-blocks per XCD with a common k start (measured: HBM reads -7 %,
                                      // time +13 % -- prefetching workgroups drift apart) (RCGP_GRAD_ORDER)
-  int heavy_mode = 1;                // 1: one persistent k_heavy_update per finished panel instead of window pieces + bulk kernel (RCGP_HEAVY)
+  int dloop = 0;                     // 1: the diagonal kernel is one resident workgroup for the whole factorisation (k_diag_loop) and the tile
+                                     // solve reads the inverse from global memory (k_prep1g: 17 KB of LDS) -- no whole-CU launch on the chain (RCGP_DLOOP)
+  bool dloop_attr_set = false, prepg_attr_set = false;
+  uint64_t* sig_ready = nullptr;     // signal memory: block jb may be factored (raised by a stream op behind P(jb-1))
+  uint64_t* sig_done = nullptr;      // signal memory: blocks < value - base are factored and inverted
+  uint64_t dl_base = 0;              // base value of the current factorisation (grows by 2^20 per factorisation)
+  int heavy_mode = 0;                // 1: one persistent k_heavy_update per finished panel instead of window pieces + bulk kernel (RCGP_HEAVY)
   int heavy_reserve_mod = 2;         // its workgroups stay off cu 4 of every heavy_reserve_mod-th shader engine (1: 32 CUs, 2: 16, 4: 8; 0: none) (RCGP_HEAVY_RESERVE)
   uint64_t* sig_flag = nullptr;      // 8 bytes of signal memory: progress word of the heavy update (hipStreamWaitValue64)
   uint64_t sig_value = 0;            // last value handed out (monotonic over the life of the handle)
   int* heavy_ctr = nullptr;          // device: two counters per outer panel, zeroed at the start of every factorisation
+  bool bulk_after_piece = false;     // a panel's bulk update waits for the panel's first window piece (RCGP_BULK_AFTER_PIECE)
   bool t2_after_p = false;           // the panel solve waits for the chain's solved tile instead of the diagonal kernel (RCGP_T2WAIT)
   bool short_k = true;               // K = 128 kernels of the panel chain request all their operand slabs up front (RCGP_SHORTK)
   bool chain_split = true;           // near / far split of the chain's column update (RCGP_SPLIT)
@@ -214,6 +221,8 @@ int rc_launch_prep_split(rcgp_handle_s* h, double* T, double* D, int64_t ld, con
 // the same with the tile solved by blocked forward substitution against L_jj itself (k_prep1s: needs only the 16x16 diagonal-block
 // inverses, which the factor-only diagonal kernel leaves in invL); the right-hand side is not touched
 int rc_launch_prep_subst(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL);
+// k_prep1g (the inverse read straight from global memory into MFMA fragments: 17 KB of LDS, fits any free slot) + k_prep2
+int rc_launch_prep_g(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
 // L^-1 by recursive doubling, level s: T = B * Ainv (lower-tri Ainv) for C-part row tiles [ti0, ti0+nti) of pairs
 // [pair0, pair0+npairs); X21 = -Cinv * T for whole pairs
 int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti0, int nti);
@@ -230,6 +239,7 @@ int rc_launch_vtv(rcgp_handle_s* h, int64_t rows_padded, const double* V, double
 
 // ---- potrf.hip
 int rc_potrf(rcgp_handle_s* h);                              // blocked Cholesky of A in place, w = L^-1 y, logdiag
+int rc_launch_diag_loop(rcgp_handle_s* h, unsigned long long base);   // the resident diagonal workgroup (k_diag_loop) on h->launch
 int rc_launch_diag(rcgp_handle_s* h, int64_t j, int mode = 0);   // diagonal block at row/col offset j: 0 = factor + invert + w_j, 1 = factor only, 2 = invert + w_j
 
 // ---- solve.hip

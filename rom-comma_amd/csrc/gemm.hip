@@ -734,6 +734,85 @@ __global__ void __launch_bounds__(256) k_prep1s(double* T, int64_t ld, const dou
   }
 }
 
+// k_prep1 with the inverse of L_jj read straight from global memory (L2) into the MFMA B fragments instead of through LDS: 17 KB of LDS
+// and 512 threads, so the workgroup fits into ANY free slot of a CU next to a resident GEMM workgroup -- k_prep1's 138 KB need a CU
+// with both slots free at once, for which it waited milliseconds at C2 (kernel trace). One 16-row strip of the tile per workgroup,
+// wave w the column tile w (k-blocks 0..w of the triangular inverse); every global load issued before the first wait.
+__global__ void __launch_bounds__(512) k_prep1g(double* T, int64_t ld, const double* __restrict__ invL, double* rhs, const double* __restrict__ wj) {
+  __shared__ double Ts[16 * LP];
+  __shared__ double red[8 * 16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
+  const int r0 = 16 * blockIdx.x, jt = wave;
+  double2 vt[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = t + 512 * q, i = e >> 6, j2 = (e & 63) * 2;
+    vt[q] = *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2);
+  }
+  double bv[8][4];
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) bv[kt][s2] = (kt <= jt) ? invL[(16 * jt + fr) * 128 + 16 * kt + 4 * s2 + fq] : 0.0;
+  const double w = wj[16 * jt + fr];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = t + 512 * q, i = e >> 6, j2 = (e & 63) * 2;
+    Ts[i * LP + j2] = vt[q].x;
+    Ts[i * LP + j2 + 1] = vt[q].y;
+  }
+  __syncthreads();
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) {
+    if (kt <= jt) {
+      double av[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) av[s2] = Ts[fr * LP + 16 * kt + 4 * s2 + fq];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[kt][s2], acc, 0, 0, 0);
+    }
+  }
+  double part[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    T[(int64_t)(r0 + fq + 4 * q) * ld + 16 * jt + fr] = acc[q];
+    double v = acc[q] * w;
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    part[q] = v;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (fr == 0) red[wave * 16 + fq + 4 * q] = part[q];
+  __syncthreads();
+  if (t < 16) {
+    const double v = ((red[t] + red[16 + t]) + (red[32 + t] + red[48 + t])) + ((red[64 + t] + red[80 + t]) + (red[96 + t] + red[112 + t]));
+    rhs[r0 + t] -= v;
+  }
+}
+
+int rc_launch_prep_g(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
+  const size_t lds2 = (size_t)(64 * LP) * sizeof(double);
+  if (!h->prepg_attr_set) {
+    RC_HIP(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    h->prepg_attr_set = true;
+  }
+  {
+    RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
+    RC_LAUNCH(k_prep1g, dim3(8), dim3(512), 0, T, ld, invL, rhs, wj);
+    RC_HIP(hipGetLastError());
+  }
+  {
+    RcProfScope ps(h, RC_K_GEMM, 128.0 * 129.0 * 128.0, true);
+    RC_LAUNCH(k_prep2, dim3(10), dim3(256), lds2, (const double*)T, D, ld);
+    RC_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
 int rc_launch_prep_subst(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL) {
   const size_t lds1 = (size_t)(128 * LP + 16 * LP) * sizeof(double), lds2 = (size_t)(64 * LP) * sizeof(double);
   if (!h->prep_s_attr_set) {

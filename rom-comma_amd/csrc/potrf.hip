@@ -338,9 +338,9 @@ __device__ __forceinline__ double xval(const double* S, const double* Xd, int i,
 // of its own on the column-work stream: reads L_jj and the diagonal-block inverses back, completes the right-hand side rows of
 // this block (rhs_j -= L(j, j-1) w_{j-1}: the block row the chain no longer updates), inverts, emits invL and w_j.
 template <int MODE>
-__global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
-                                               double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
-  extern __shared__ double S[];                    // [128][LS], then Xd[8][16][XS], rsd[128], rv[128]
+__device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
+                                           double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
+  // S: [128][LS], then Xd[8][16][XS], rsd[128], rv[128]   (dynamic shared memory of the calling kernel)
   double* Xd = S + 128 * LS;
   double* rsd = Xd + 8 * 16 * XS;
   double* rv = rsd + 128;
@@ -559,6 +559,68 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
   RC_T(23);
 }
 
+template <int MODE>
+__global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
+                                               double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
+  extern __shared__ double S[];
+  diag2_body<MODE>(S, A, ld, invL, rhs, logdiag, info, j0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_diag_loop: the diagonal kernel as ONE RESIDENT workgroup for the whole factorisation (RCGP_DLOOP=1). A kernel trace of the C2
+// factorisation shows the chain's whole-CU kernels waiting MILLISECONDS for a CU while window pieces, bulk updates and column work
+// keep both slots of every CU turning over out of phase; a workgroup that never leaves its CU cannot starve. It walks the diagonal
+// blocks in order: waits until the host-side stream op behind P(jb-1) has raised `ready` to base + jb (hipStreamWriteValue64),
+// acquires, factors + inverts block jb exactly as k_diag2<0> does, releases, raises `done` to base + jb + 1 -- the panel solve and
+// the tile solve of that block wait for it with hipStreamWaitValue64. Every wait is bounded (wall clock): on a time-out the kernel
+// flags the factorisation as failed (info = -9) and raises `done` past the last block, so no stream is left waiting.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_diag_loop(double* __restrict__ A, int64_t ld, double* __restrict__ invdiag, double* __restrict__ rhs,
+                                                   double* __restrict__ logdiag, int* __restrict__ info, int nblocks,
+                                                   unsigned long long* ready, unsigned long long* done, unsigned long long base) {
+  extern __shared__ double S[];
+  __shared__ int s_abort;
+  if (threadIdx.x == 0) s_abort = 0;
+  __syncthreads();
+  for (int jb = 0; jb < nblocks; ++jb) {
+    if (jb > 0) {
+      if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < base + (unsigned long long)jb) {
+          __builtin_amdgcn_s_sleep(8);
+          if (wall_clock64() - t0 > 200000000ll) { s_abort = 1; break; }          // 2 s at 100 MHz
+        }
+      }
+      __syncthreads();
+      if (s_abort) {
+        if (threadIdx.x == 0) {
+          atomicExch(info, -9);
+          __hip_atomic_store(done, base + (unsigned long long)nblocks + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // what the update kernels wrote is read from memory, not from a stale line
+    }
+    diag2_body<0>(S, A, ld, invdiag + (size_t)jb * 128 * 128, rhs, logdiag, info, (int64_t)jb * 128);
+    __threadfence();                                                   // L_jj, its inverse, w_j: out to memory before the word that announces them
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done, base + (unsigned long long)jb + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+int rc_launch_diag_loop(rcgp_handle_s* h, unsigned long long base) {
+  const size_t lds = (size_t)(128 * LS + 8 * 16 * XS + 256 + 32 + 256) * sizeof(double);
+  if (!h->dloop_attr_set) {
+    RC_HIP(hipFuncSetAttribute((const void*)k_diag_loop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->dloop_attr_set = true;
+  }
+  RcProfScope ps(h, RC_K_DIAG, (double)(h->Np / 128) * 128.0 * 128.0 * 128.0 / 3.0, true);
+  RC_LAUNCH(k_diag_loop, dim3(1), dim3(512), lds, h->A, h->Np, h->invdiag, h->w, h->logdiag, h->info, (int)(h->Np / 128),
+            (unsigned long long*)h->sig_ready, (unsigned long long*)h->sig_done, base);
+  RC_HIP(hipGetLastError());
+  return 0;
+}
+
 int rc_launch_diag(rcgp_handle_s* h, int64_t j, int mode) {
   RcProfScope ps(h, RC_K_DIAG, mode == 2 ? 0.0 : 128.0 * 128.0 * 128.0 / 3.0, true);
   double* inv = h->invdiag + (j / 128) * 128 * 128;
@@ -669,13 +731,36 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
   // t2p: the panel solve T2(j) waits for P(j)'s solved tile instead of D(j), so that D(j) carries no completion event (a dispatch that
   // carries one delays its successor on the stream by ~5 us: kernel trace)
   const bool t2p = h->t2_after_p && !late;
+  // dloop: the diagonal blocks are factored by ONE resident workgroup (k_diag_loop on stream4, launched here, before anything can crowd
+  // it out); "block j is factored" and "block j may be factored" are values in two signal words, waited for / raised by stream
+  // memory operations, and the chain's tile solve is the small-LDS k_prep1g
+  const bool dloop = h->dloop && h->sig_ready && h->sig_done && h->stream4 && !late && h->diag_variant != 1 && h->chain_ext >= 2 && !h->profiling;
+  uint64_t dl_base = 0;
+  hipEvent_t eDL = nullptr;
+  if (dloop) {
+    h->dl_base += (1ull << 20);
+    dl_base = h->dl_base;
+    if ((rc = next_event(h, &eDL))) return rc;
+    RC_HIP(hipStreamWaitEvent(h->stream4, e0, 0));
+    h->launch = h->stream4;
+    if (ext) h->launch_stop = eDL;
+    if ((rc = rc_launch_diag_loop(h, dl_base)) || (rc = flush_stop(h))) return rc;
+    if (!ext) RC_HIP(hipEventRecord(eDL, h->stream4));
+  }
   for (int64_t j = 0; j < Np; j += 128) {
     const int64_t below = Np - (j + 128);
     hipEvent_t eD = nullptr, eP, eG;
     if ((below > 0 || late) && (rc = next_event(h, &eD))) return rc;
     h->launch = C;
+    if (dloop) {
+      // D(j) runs inside the resident kernel: C and B wait for its word instead of an event
+      const uint64_t want = dl_base + (uint64_t)(j / 128) + 1;
+      RC_HIP(hipStreamWaitValue64(C, h->sig_done, want, hipStreamWaitValueGte, 0xffffffffffffffffull));
+      if (below > 0) RC_HIP(hipStreamWaitValue64(B, h->sig_done, want, hipStreamWaitValueGte, 0xffffffffffffffffull));
+    } else {
     if (ext && !t2p) h->launch_stop = eD;
     if ((rc = rc_launch_diag(h, j, late ? 1 : 0)) || (rc = flush_stop(h))) return rc;
+    }
     if (late) {
       if (!ext) RC_HIP(hipEventRecord(eD, C));
       RC_HIP(hipStreamWaitEvent(B, eD, 0));
@@ -690,7 +775,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     double* P = h->A + (j + 128) * Np + j;                       // rows below the diagonal block, 128 columns
     const double* inv = h->invdiag + (j / 128) * 128 * 128;
     if ((rc = next_event(h, &eP)) || (rc = next_event(h, &eG))) return rc;
-    if (!late && !t2p) {
+    if (!late && !t2p && !dloop) {
       if (!ext) RC_HIP(hipEventRecord(eD, C));
       RC_HIP(hipStreamWaitEvent(B, eD, 0));
     }
@@ -699,12 +784,16 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     if (ext) h->launch_stop = eP;                                 // (with the split: taken by k_prep1 -- the column work needs the solved tile only)
     if (late)
       rc = rc_launch_prep_subst(h, P, h->A + (j + 128) * Np + (j + 128), Np, h->A + j * Np + j, inv);
+    else if (dloop)
+      rc = rc_launch_prep_g(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j);
     else if (h->prep_split)
       rc = rc_launch_prep_split(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j);
     else
       rc = rc_launch_prep_next(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j);
     if (rc || (rc = flush_stop(h))) return rc;
     if (!ext) RC_HIP(hipEventRecord(eP, C));
+    if (dloop)                                                    // behind P(j) in C's order: the next diagonal block is complete
+      RC_HIP(hipStreamWriteValue64(C, h->sig_ready, dl_base + (uint64_t)(j / 128) + 1, 0));
     h->launch = B;
     if (t2p) RC_HIP(hipStreamWaitEvent(B, eP, 0));
     hipEvent_t ePanel = eG;                                       // everything of this step on B (and B2) done
@@ -812,6 +901,9 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
         } else {                                                  // bulk: everything from u0 on
           if ((rc = next_event(h, &eR_new))) return rc;
           RC_HIP(hipStreamWaitEvent(U2, eG, 0));
+          // bulk_after_piece: the bulk kernel of this panel starts only when the panel's FIRST window piece -- the update the chain is
+          // waiting for -- is done, so that the piece has the chip (beside the previous bulk kernel's tail) instead of a third of it
+          if (h->bulk_after_piece && eU1_prev) RC_HIP(hipStreamWaitEvent(U2, eU1_prev, 0));
           h->launch = U2;
           if (ext) h->launch_stop = eR_new;
           if ((rc = rc_launch_syrk_lower(h, h->A + u0 * Np + u0, Np, Lp0 + u0 * Np, Np, Np - u0, NB)) || (rc = flush_stop(h))) return rc;
@@ -836,6 +928,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
   RC_HIP(hipStreamWaitEvent(h->stream, eC, 0));
   RC_HIP(hipStreamWaitEvent(h->stream, eB, 0));
   RC_HIP(hipStreamWaitEvent(h->stream, eB2, 0));
+  if (eDL) RC_HIP(hipStreamWaitEvent(h->stream, eDL, 0));
   if (eU2_prev) RC_HIP(hipStreamWaitEvent(h->stream, eU2_prev, 0));
   if (overlap_inverse) {
     RC_HIP(hipEventRecord(h->ev_inv, h->stream4));
