@@ -84,7 +84,7 @@ static void release_streams(rcgp_handle_s* h) {
 
 static void free_all(rcgp_handle_s* h) {
   double** bufs[] = {&h->X, &h->Z, &h->sq, &h->y, &h->w, &h->alpha, &h->A, &h->Linv, &h->S, &h->invdiag, &h->logdiag, &h->partial,
-                     &h->scal, &h->ell_d, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob, &h->gV, &h->gC};
+                     &h->scal, &h->ell_d, &h->tile_tmp, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob, &h->gV, &h->gC};
   for (auto b : bufs)
     if (*b) { hipFree(*b); *b = nullptr; }
   h->info = nullptr;                                       // (inside scal)
@@ -219,6 +219,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   if (const char* e = getenv("RCGP_BULK_AFTER_PIECE")) h->bulk_after_piece = (e[0] != '0');
   if (const char* e = getenv("RCGP_HEAVY")) h->heavy_mode = atoi(e);
   if (const char* e = getenv("RCGP_DLOOP")) h->dloop = atoi(e);
+  if (const char* e = getenv("RCGP_PREP_SMALL")) h->prep_small = (e[0] != '0');
   if (h->dloop) {
     int can = 0;
     if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess || !can ||
@@ -241,9 +242,10 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
       h->heavy_mode = 0;                               // no stream wait-value on this device: window pieces + bulk kernels
     } else {
       RC_HIP(hipMemsetAsync(h->sig_flag, 0, sizeof(uint64_t), h->stream));
-      RC_HIP(hipMalloc(&h->heavy_ctr, 2 * RC_MAX_PANELS * sizeof(int)));
     }
   }
+  RC_HIP(hipMalloc(&h->heavy_ctr, (2 * RC_MAX_PANELS + 2) * sizeof(int)));       // heavy-update counters per panel + k_prep2r's arrival counter
+  RC_HIP(hipMemsetAsync(h->heavy_ctr, 0, (2 * RC_MAX_PANELS + 2) * sizeof(int), h->stream));
   if (const char* e = getenv("RCGP_INV_EVERY")) {
     const int x = atoi(e);
     if (x >= 1) h->inv_every = x;

@@ -48,9 +48,10 @@ struct rcgp_handle_s {
   bool prep_attr_set = false, prep_s_attr_set = false;
   int grad_order = 0;                // k_grad tile order: 0 = heavy-first rows; 1 = 8 x 8 super-blocks per XCD with a common k start (measured: HBM reads -7 %,
                                      // time +13 % -- prefetching workgroups drift apart) (RCGP_GRAD_ORDER)
+  bool prep_small = false;           // the tile solve as 32 small workgroups (k_prep1q + k_prep2r) instead of 8 whole-CU ones (RCGP_PREP_SMALL)
   int dloop = 0;                     // 1: the diagonal kernel is one resident workgroup for the whole factorisation (k_diag_loop) and the tile
                                      // solve reads the inverse from global memory (k_prep1g: 17 KB of LDS) -- no whole-CU launch on the chain (RCGP_DLOOP)
-  bool dloop_attr_set = false, prepg_attr_set = false;
+  bool dloop_attr_set = false, prepg_attr_set = false, prepq_attr_set = false;
   uint64_t* sig_ready = nullptr;     // signal memory: block jb may be factored (raised by a stream op behind P(jb-1))
   uint64_t* sig_done = nullptr;      // signal memory: blocks < value - base are factored and inverted
   uint64_t dl_base = 0;              // base value of the current factorisation (grows by 2^20 per factorisation)
@@ -125,6 +126,7 @@ struct rcgp_handle_s {
   int64_t pred_cap = 0;        // rows of KsT / pmean / pvar
   int64_t pts_cap = 0;         // points Xs / Zs / sqs hold (>= pred_cap; predict_gradient grows it)
   double *gV = nullptr, *gC = nullptr;   // predict_gradient scratch
+  double *tile_tmp = nullptr;            // one dense 128 x 128 tile: the chain's solved tile between k_prep1q and k_prep2r
   int64_t g_rows = 0;
   int g_blocks = 0;                       // V^T V products gC has room for
   // sobol scratch
@@ -223,6 +225,9 @@ int rc_launch_prep_split(rcgp_handle_s* h, double* T, double* D, int64_t ld, con
 int rc_launch_prep_subst(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL);
 // k_prep1g (the inverse read straight from global memory into MFMA fragments: 17 KB of LDS, fits any free slot) + k_prep2
 int rc_launch_prep_g(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
+// k_prep1q (32 small workgroups, 49.5 KB of LDS) + k_prep2r (diagonal-block update, rhs rows, optional `ready` signal of the resident diagonal workgroup)
+int rc_launch_prep_q(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj, int* ctr,
+                     unsigned long long* ready, unsigned long long value);
 // L^-1 by recursive doubling, level s: T = B * Ainv (lower-tri Ainv) for C-part row tiles [ti0, ti0+nti) of pairs
 // [pair0, pair0+npairs); X21 = -Cinv * T for whole pairs
 int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti0, int nti);

@@ -794,6 +794,173 @@ __global__ void __launch_bounds__(512) k_prep1g(double* T, int64_t ld, const dou
   }
 }
 
+// k_prep1q: the chain's tile solve in 32 small workgroups (8 strips of 16 rows x 4 groups of two 16-column tiles), each staging only the
+// rows of the inverse its two column tiles need: 49.5 KB of LDS and 128 threads, so a workgroup fits into whatever is free beside a resident
+// GEMM workgroup -- and the loads stay coalesced row pieces, unlike k_prep1g's scattered fragment loads (49 us against 7). Wave w of group g
+// computes column tile 2 g + w. The solved tile goes to a dense scratch tile (the groups of a strip read each other's input columns, so nothing may
+// be written in place); k_prep2r reads it from there, copies it into the matrix and updates the right-hand side rows (a product over ALL columns).
+__global__ void __launch_bounds__(128) k_prep1q(const double* __restrict__ T, int64_t ld, const double* __restrict__ invL, double* __restrict__ Xout) {
+  extern __shared__ double smq[];                  // Ts[16][LP], Is[32][LP]
+  double* Ts = smq;
+  double* Is = Ts + 16 * LP;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
+  const int r0 = 16 * (blockIdx.x & 7), g = blockIdx.x >> 3;
+  const int c0 = 32 * g;                           // first column (= first row of the inverse) of this group
+  const int kmax = 32 * g + 32;                    // the triangular inverse: row c has entries k <= c only
+  double2 vt[8], vi[16];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = t + 128 * q, i = e >> 6, j2 = (e & 63) * 2;
+    vt[q] = (j2 < kmax) ? *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2) : make_double2(0.0, 0.0);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = t + 128 * q, i = e >> 6, j2 = (e & 63) * 2;
+    vi[q] = (j2 <= c0 + i) ? *reinterpret_cast<const double2*>(invL + (c0 + i) * 128 + j2) : make_double2(0.0, 0.0);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = t + 128 * q, i = e >> 6, j2 = (e & 63) * 2;
+    Ts[i * LP + j2] = vt[q].x;
+    Ts[i * LP + j2 + 1] = vt[q].y;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = t + 128 * q, i = e >> 6, j2 = (e & 63) * 2;
+    Is[i * LP + j2] = vi[q].x;
+    Is[i * LP + j2 + 1] = (j2 + 1 <= c0 + i) ? vi[q].y : 0.0;
+  }
+  __syncthreads();
+  const int jt = 2 * g + wave;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  for (int kt = 0; kt <= jt; ++kt) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      av[s2] = Ts[fr * LP + 16 * kt + 4 * s2 + fq];
+      bv[s2] = Is[(16 * wave + fr) * LP + 16 * kt + 4 * s2 + fq];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
+  }
+#pragma unroll
+  // OUT OF PLACE (dense 128 x 128 scratch): the other column groups of this strip are still reading the tile
+  for (int q = 0; q < 4; ++q) Xout[(r0 + fq + 4 * q) * 128 + 16 * jt + fr] = acc[q];
+}
+
+// k_prep2 plus (a) workgroup 10: the right-hand side rows of the block, rhs -= X w_j over all 128 columns of the solved tile (fixed order),
+// and (b) optionally the signal of the resident diagonal workgroup: the LAST of the 11 workgroups to finish raises `ready` to `value`
+// (counter ctr, reset for the next launch: launches of this kernel follow each other on one stream).
+__global__ void __launch_bounds__(256) k_prep2r(const double* __restrict__ Lt, double* __restrict__ Tdst, double* D, int64_t ld, double* rhs,
+                                                const double* __restrict__ wj, int* ctr, unsigned long long* ready, unsigned long long value) {
+  extern __shared__ double sm2[];                  // La[32][LP], Lb[32][LP]
+  const int t = threadIdx.x;
+  if (blockIdx.x == 10) {
+    const int i = t >> 1, half = t & 1;
+    const double* row = Lt + i * 128 + 64 * half;
+    double* dst = Tdst + (int64_t)i * ld + 64 * half;
+    const double* wv = wj + 64 * half;
+    double sacc = 0.0;
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) {                    // 16 sixteen-byte loads of the row in flight at a time
+      double2 xv[16], wv2[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        xv[q] = *reinterpret_cast<const double2*>(row + 32 * c + 2 * q);
+        wv2[q] = *reinterpret_cast<const double2*>(wv + 32 * c + 2 * q);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        *reinterpret_cast<double2*>(dst + 32 * c + 2 * q) = xv[q];            // the solved tile into the matrix
+        sacc = __builtin_fma(xv[q].y, wv2[q].y, __builtin_fma(xv[q].x, wv2[q].x, sacc));
+      }
+    }
+    const double other = __shfl_xor(sacc, 1);
+    if (half == 0) rhs[i] -= (sacc + other);
+  } else {
+    double* La = sm2;
+    double* Lb = La + 32 * LP;
+    const int lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
+    int bi = 0, rem = blockIdx.x;
+    while (rem > bi) { rem -= bi + 1; ++bi; }
+    const int bj = rem;
+    double2 va[8], vb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
+      va[q] = *reinterpret_cast<const double2*>(Lt + (32 * bi + i) * 128 + j2);
+      vb[q] = *reinterpret_cast<const double2*>(Lt + (32 * bj + i) * 128 + j2);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
+      La[i * LP + j2] = va[q].x;
+      La[i * LP + j2 + 1] = va[q].y;
+      Lb[i * LP + j2] = vb[q].x;
+      Lb[i * LP + j2 + 1] = vb[q].y;
+    }
+    const int ti = wave >> 1, tj = wave & 1;
+    double* Dt = D + (int64_t)(32 * bi + 16 * ti) * ld + 32 * bj + 16 * tj;
+    const bool needed = !(bi == bj && tj > ti);
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    if (needed) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = Dt[(int64_t)(fq + 4 * q) * ld + fr];
+    }
+    __syncthreads();
+    if (needed) {
+#pragma unroll 2
+      for (int kt = 0; kt < 8; ++kt) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          av[s2] = La[(16 * ti + fr) * LP + 16 * kt + 4 * s2 + fq];
+          bv[s2] = Lb[(16 * tj + fr) * LP + 16 * kt + 4 * s2 + fq];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 1);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Dt[(int64_t)(fq + 4 * q) * ld + fr] = acc[q];
+    }
+  }
+  if (ready) {
+    __threadfence();
+    __syncthreads();
+    if (t == 0 && atomicAdd(ctr, 1) == (int)gridDim.x - 1) {
+      atomicExch(ctr, 0);
+      __threadfence();
+      __hip_atomic_store(ready, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// tile solve in small workgroups + diagonal-block update + rhs rows (+ the resident diagonal workgroup's signal when ready != null)
+int rc_launch_prep_q(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj, int* ctr,
+                     unsigned long long* ready, unsigned long long value) {
+  const size_t lds1 = (size_t)(48 * LP) * sizeof(double), lds2 = (size_t)(64 * LP) * sizeof(double);
+  if (!h->prepq_attr_set) {
+    RC_HIP(hipFuncSetAttribute((const void*)k_prep1q, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    RC_HIP(hipFuncSetAttribute((const void*)k_prep2r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    h->prepq_attr_set = true;
+  }
+  if (!h->tile_tmp) RC_HIP(hipMalloc(&h->tile_tmp, 128 * 128 * sizeof(double)));
+  hipEvent_t ev = h->launch_stop;                    // "the tile is solved" is true only after k_prep2r has copied it into the matrix
+  h->launch_stop = nullptr;
+  {
+    RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
+    RC_LAUNCH(k_prep1q, dim3(32), dim3(128), lds1, (const double*)T, ld, invL, h->tile_tmp);
+    RC_HIP(hipGetLastError());
+  }
+  h->launch_stop = ev;
+  {
+    RcProfScope ps(h, RC_K_GEMM, 128.0 * 129.0 * 128.0, true);
+    RC_LAUNCH(k_prep2r, dim3(11), dim3(256), lds2, (const double*)h->tile_tmp, T, D, ld, rhs, wj, ctr, ready, value);
+    RC_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
 int rc_launch_prep_g(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
   const size_t lds2 = (size_t)(64 * LP) * sizeof(double);
   if (!h->prepg_attr_set) {

@@ -785,14 +785,19 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     if (late)
       rc = rc_launch_prep_subst(h, P, h->A + (j + 128) * Np + (j + 128), Np, h->A + j * Np + j, inv);
     else if (dloop)
-      rc = rc_launch_prep_g(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j);
+      rc = (h->dloop == 2)
+               ? rc_launch_prep_g(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j)
+               : rc_launch_prep_q(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j, h->heavy_ctr + 2 * RC_MAX_PANELS,
+                                  (unsigned long long*)h->sig_ready, dl_base + (uint64_t)(j / 128) + 1);
+    else if (h->prep_small)
+      rc = rc_launch_prep_q(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j, nullptr, nullptr, 0);
     else if (h->prep_split)
       rc = rc_launch_prep_split(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j);
     else
       rc = rc_launch_prep_next(h, P, h->A + (j + 128) * Np + (j + 128), Np, inv, h->w + j + 128, h->w + j);
     if (rc || (rc = flush_stop(h))) return rc;
     if (!ext) RC_HIP(hipEventRecord(eP, C));
-    if (dloop)                                                    // behind P(j) in C's order: the next diagonal block is complete
+    if (dloop && h->dloop == 2)                                   // (variant 2: a stream memory op raises the word; variant 1: k_prep2r's last workgroup)
       RC_HIP(hipStreamWriteValue64(C, h->sig_ready, dl_base + (uint64_t)(j / 128) + 1, 0));
     h->launch = B;
     if (t2p) RC_HIP(hipStreamWaitEvent(B, eP, 0));
