@@ -119,6 +119,28 @@ __global__ void __launch_bounds__(512, 4) k_gram(double* __restrict__ out, int64
         acc[a][2 * b + 1] = fma(ra[a], cb[b].y, acc[a][2 * b + 1]);
       }
   }
+  // Interior tiles -- off the diagonal of their block pair and entirely inside the valid rows and columns: all but O(T) of the T^2/2
+  // tiles -- need none of the per-element noise / padding tests (four 64-bit compares and selects per pair of outputs, a fifth of the
+  // kernel's VALU work at M = 10, and the kernel is VALU-bound, not store-bound: 8- and 16-byte, temporal and nontemporal stores all
+  // give the same time).
+  const int64_t i_lo = (int64_t)ti * 128 - ioff, j_lo = (int64_t)tj * 128 - joff;
+  const bool interior = (CROSS || i_lo != j_lo || bi != bj) && i_lo + 128 <= nr_valid && j_lo + 128 <= nc_valid &&
+                        (CROSS || i_lo >= j_lo + 128 || j_lo >= i_lo + 128);
+  if (interior) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = ty + 32 * a;
+      const double sia = si[row];
+      double* dst_row = out + ((int64_t)ti * 128 + row) * ld + (int64_t)tj * 128;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int col = 2 * tx + 32 * b;
+        __builtin_nontemporal_store(var * rc_exp(sia + sj[col] + acc[a][2 * b]), dst_row + col);
+        __builtin_nontemporal_store(var * rc_exp(sia + sj[col + 1] + acc[a][2 * b + 1]), dst_row + col + 1);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int row = ty + 32 * a;
