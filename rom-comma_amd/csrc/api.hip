@@ -217,6 +217,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   if (const char* e = getenv("RCGP_GRAD_ORDER")) h->grad_order = atoi(e);
   if (const char* e = getenv("RCGP_T2WAIT")) h->t2_after_p = (e[0] != '0');
   if (const char* e = getenv("RCGP_BULK_AFTER_PIECE")) h->bulk_after_piece = (e[0] != '0');
+  if (const char* e = getenv("RCGP_PIECES_ON_BULK")) h->pieces_on_bulk = (e[0] != '0');
   if (const char* e = getenv("RCGP_HEAVY")) h->heavy_mode = atoi(e);
   if (const char* e = getenv("RCGP_DLOOP")) h->dloop = atoi(e);
   if (const char* e = getenv("RCGP_PREP_SMALL")) h->prep_small = (e[0] != '0');

@@ -887,9 +887,12 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
         if (u0 >= Np) break;
         const int64_t u1 = (u0 + NB < Np) ? u0 + NB : Np;
         if (q < depth) {                                          // window piece
-          if (q == 0) RC_HIP(hipStreamWaitEvent(U1, eG, 0));
-          if (q == depth - 1 && eU2_prev) RC_HIP(hipStreamWaitEvent(U1, eU2_prev, 0));   // this panel was in the previous bulk kernel
-          h->launch = U1;
+          // pieces_on_bulk: the pieces go down the bulk stream, ahead of their panel's bulk kernel -- with RCGP_RESERVE_CUS that is ONE
+          // CU-masked queue for every K = NB kernel (two active masked queues put the runtime in its slow regime)
+          hipStream_t PS = h->pieces_on_bulk ? U2 : U1;
+          if (q == 0) RC_HIP(hipStreamWaitEvent(PS, eG, 0));
+          if (q == depth - 1 && eU2_prev && PS != U2) RC_HIP(hipStreamWaitEvent(PS, eU2_prev, 0));   // this panel was in the previous bulk kernel
+          h->launch = PS;
           hipEvent_t eU1 = nullptr;
           if (q == 0) {
             if ((rc = next_event(h, &eU1))) return rc;
@@ -899,7 +902,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
               (rc = flush_stop(h)))
             return rc;
           if (q == 0) {
-            if (!ext) RC_HIP(hipEventRecord(eU1, U1));
+            if (!ext) RC_HIP(hipEventRecord(eU1, PS));
             eU1_prev = eU1;
             have_win = true;
           }

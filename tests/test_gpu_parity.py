@@ -336,7 +336,7 @@ def test_sobol_error_terms(gpu, L):
                                  {'RCGP_NB': '256', 'RCGP_EXT': '1', 'RCGP_DEPTH': '1'}, {'RCGP_NB': '128', 'RCGP_EXT': '3', 'RCGP_DEPTH': '8'},
                                  {'RCGP_NB': '384', 'RCGP_DEPTH': '2'}, {'RCGP_OVERLAP_INVERSE': '1', 'RCGP_INV_EVERY': '1', 'RCGP_NB': '256'},
                                  {'RCGP_EXTEV': '0'}, {'RCGP_SPLIT': '0'}, {'RCGP_PSPLIT': '3'}, {'RCGP_SHORTK': '0'}, {'RCGP_GRAD_ORDER': '1'}, {'RCGP_HEAVY': '1'}, {'RCGP_HEAVY': '1', 'RCGP_HEAVY_RESERVE': '1', 'RCGP_NB': '256'},
-                                 {'RCGP_DLOOP': '1'}, {'RCGP_DLOOP': '2', 'RCGP_NB': '384'}, {'RCGP_PREP_SMALL': '1'}, {'RCGP_BULK_AFTER_PIECE': '1'}, {'RCGP_T2WAIT': '1'}, {'RCGP_PSPLIT': '3', 'RCGP_SHORTK': '0', 'RCGP_NB': '256'}, {'RCGP_SPLIT': '0', 'RCGP_EXT': '2', 'RCGP_DEPTH': '4'},
+                                 {'RCGP_DLOOP': '1'}, {'RCGP_DLOOP': '2', 'RCGP_NB': '384'}, {'RCGP_PREP_SMALL': '1'}, {'RCGP_BULK_AFTER_PIECE': '1'}, {'RCGP_T2WAIT': '1'}, {'RCGP_PIECES_ON_BULK': '1', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_PSPLIT': '3', 'RCGP_SHORTK': '0', 'RCGP_NB': '256'}, {'RCGP_SPLIT': '0', 'RCGP_EXT': '2', 'RCGP_DEPTH': '4'},
                                  {'RCGP_EXT': '2'}, {'RCGP_EXT': '6', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_PSPLIT': '0'}, {'RCGP_PSPLIT': '1'}])
 def test_tuning_knobs_do_not_change_results(gpu, env, monkeypatch):
     """Every run-time variant (register-sweep diagonal kernel, sequential Cholesky, no reserved CUs, overlapped inverse, coarse
