@@ -129,10 +129,17 @@ static int upload_targets(rcgp_handle_s* h, const double* Y) {
 }
 
 static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
-  RC_HIP(hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking));
+  // RCGP_LOWPRIO: 1 = the bulk-update stream at the LOWEST priority, 2 = the main stream (window pieces) as well
+  int lowprio = 0;
+  if (const char* e = getenv("RCGP_LOWPRIO")) lowprio = atoi(e);
+  int lo = 0, hi = 0;
+  RC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));            // hi is the numerically lowest = highest priority
+  if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] stream priorities: least %d, greatest %d\n", lo, hi);
+  if (lowprio >= 2)
+    RC_HIP(hipStreamCreateWithPriority(&ds.stream, hipStreamNonBlocking, lo));
+  else
+    RC_HIP(hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking));
   {
-    int lo = 0, hi = 0;
-    RC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // hi is the numerically lowest = highest priority
     RC_HIP(hipStreamCreateWithPriority(&ds.stream2, hipStreamNonBlocking, hi));
     RC_HIP(hipStreamCreateWithPriority(&ds.stream5, hipStreamNonBlocking, hi));
     RC_HIP(hipStreamCreateWithPriority(&ds.stream6, hipStreamNonBlocking, hi));
@@ -156,7 +163,10 @@ static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
     if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] %d CUs, reserve %d, CU-mask stream: %s\n", ncu, reserve, hipGetErrorString(me));
     if (me != hipSuccess) {
       (void)hipGetLastError();
-      RC_HIP(hipStreamCreateWithFlags(&ds.stream3, hipStreamNonBlocking));
+      if (lowprio >= 1)
+        RC_HIP(hipStreamCreateWithPriority(&ds.stream3, hipStreamNonBlocking, lo));
+      else
+        RC_HIP(hipStreamCreateWithFlags(&ds.stream3, hipStreamNonBlocking));
       if (want4) RC_HIP(hipStreamCreateWithFlags(&ds.stream4, hipStreamNonBlocking));
     } else if (want4) {
       // the overlapped L^-1 kernels run long tiles: confine them to the upper part of the chip so that the panel chain's GEMMs
@@ -218,6 +228,7 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   if (const char* e = getenv("RCGP_T2WAIT")) h->t2_after_p = (e[0] != '0');
   if (const char* e = getenv("RCGP_BULK_AFTER_PIECE")) h->bulk_after_piece = (e[0] != '0');
   if (const char* e = getenv("RCGP_PIECES_ON_BULK")) h->pieces_on_bulk = (e[0] != '0');
+  if (const char* e = getenv("RCGP_CATCHUP")) h->catchup_blocks = atoi(e) > 0 ? atoi(e) : 0;
   if (const char* e = getenv("RCGP_HEAVY")) h->heavy_mode = atoi(e);
   if (const char* e = getenv("RCGP_DLOOP")) h->dloop = atoi(e);
   if (const char* e = getenv("RCGP_PREP_SMALL")) h->prep_small = (e[0] != '0');

@@ -61,6 +61,7 @@ struct rcgp_handle_s {
   uint64_t sig_value = 0;            // last value handed out (monotonic over the life of the handle)
   int* heavy_ctr = nullptr;          // device: two counters per outer panel, zeroed at the start of every factorisation
   bool pieces_on_bulk = false;       // window pieces on the bulk stream (RCGP_PIECES_ON_BULK)
+  int catchup_blocks = 0;            // block columns taller than this many blocks get ONE long-K catch-up update instead of a K=128 far update per step (RCGP_CATCHUP; 0 = off)
   bool bulk_after_piece = false;     // a panel's bulk update waits for the panel's first window piece (RCGP_BULK_AFTER_PIECE)
   bool t2_after_p = false;           // the panel solve waits for the chain's solved tile instead of the diagonal kernel (RCGP_T2WAIT)
   bool short_k = true;               // K = 128 kernels of the panel chain request all their operand slabs up front (RCGP_SHORTK)

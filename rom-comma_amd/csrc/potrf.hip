@@ -820,16 +820,38 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
           (rc = flush_stop(h)))
         return rc;
       if (!ext) RC_HIP(hipEventRecord(eG, B));
-      if (cend > nend) {
+      // Beyond the near columns: either the K=128 update of all of [nend, cend) at every step (far G), or -- for the block columns
+      // taller than catchup_blocks -- nothing until the column is three blocks ahead, then ONE update with every finished column its
+      // window pieces do not deliver, [lo, j + 128): the same flops with one read-modify-write of the column instead of one per
+      // step (K up to NB + 128 instead of 128). Panel q reaches column cc through its pieces iff cc >= (q + 1) NB + EXT.
+      const int64_t ccut = (h->catchup_blocks > 0 && Np > 128 * (int64_t)h->catchup_blocks) ? Np - 128 * (int64_t)h->catchup_blocks : 0;
+      const int64_t cc = c0 + 256;                               // the column that joins the near window at the next step
+      const int64_t lo = ((cc >= EXT) ? (cc - EXT) / NB : 0) * NB;
+      const bool do_cu = (cc < cend && cc < ccut && j + 128 > lo);
+      const int64_t f0 = (nend > ccut) ? nend : ccut;
+      const bool do_far = (cend > f0);
+      if (do_cu || do_far) {
         if ((rc = next_event(h, &eFar))) return rc;
         RC_HIP(hipStreamWaitEvent(B2, eT2, 0));
-        if (have_win && !far_waited && cend > u0_prev) { RC_HIP(wait_window(B2)); far_waited = true; }
+        if (have_win && !far_waited && ((do_far && cend > u0_prev) || (do_cu && cc + 128 > u0_prev))) {
+          RC_HIP(wait_window(B2));
+          far_waited = true;
+        }
         h->launch = B2;
-        if (ext) h->launch_stop = eFar;
-        if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + nend, Np, P + 128 * Np, Np, P + (nend - c0) * Np, Np, below - 128, cend - nend,
-                                        128, j + 256, nend)) ||
-            (rc = flush_stop(h)))
-          return rc;
+        if (do_cu) {
+          if (ext && !do_far) h->launch_stop = eFar;
+          if ((rc = rc_launch_gemm_nt_sub(h, h->A + cc * Np + cc, Np, h->A + cc * Np + lo, Np, h->A + cc * Np + lo, Np, Np - cc, 128,
+                                          j + 128 - lo, cc, cc)) ||
+              (rc = flush_stop(h)))
+            return rc;
+        }
+        if (do_far) {
+          if (ext) h->launch_stop = eFar;
+          if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + f0, Np, P + 128 * Np, Np, P + (f0 - c0) * Np, Np, below - 128, cend - f0, 128,
+                                          j + 256, f0)) ||
+              (rc = flush_stop(h)))
+            return rc;
+        }
         if (!ext) RC_HIP(hipEventRecord(eFar, B2));
         eFar_prev = eFar;
       }

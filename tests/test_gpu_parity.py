@@ -337,7 +337,9 @@ def test_sobol_error_terms(gpu, L):
                                  {'RCGP_NB': '384', 'RCGP_DEPTH': '2'}, {'RCGP_OVERLAP_INVERSE': '1', 'RCGP_INV_EVERY': '1', 'RCGP_NB': '256'},
                                  {'RCGP_EXTEV': '0'}, {'RCGP_SPLIT': '0'}, {'RCGP_PSPLIT': '3'}, {'RCGP_SHORTK': '0'}, {'RCGP_GRAD_ORDER': '1'}, {'RCGP_HEAVY': '1'}, {'RCGP_HEAVY': '1', 'RCGP_HEAVY_RESERVE': '1', 'RCGP_NB': '256'},
                                  {'RCGP_DLOOP': '1'}, {'RCGP_DLOOP': '2', 'RCGP_NB': '384'}, {'RCGP_PREP_SMALL': '1'}, {'RCGP_BULK_AFTER_PIECE': '1'}, {'RCGP_T2WAIT': '1'}, {'RCGP_PIECES_ON_BULK': '1', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_PSPLIT': '3', 'RCGP_SHORTK': '0', 'RCGP_NB': '256'}, {'RCGP_SPLIT': '0', 'RCGP_EXT': '2', 'RCGP_DEPTH': '4'},
-                                 {'RCGP_EXT': '2'}, {'RCGP_EXT': '6', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_PSPLIT': '0'}, {'RCGP_PSPLIT': '1'}])
+                                 {'RCGP_EXT': '2'}, {'RCGP_EXT': '6', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_PSPLIT': '0'}, {'RCGP_PSPLIT': '1'},
+                                 {'RCGP_CATCHUP': '4'}, {'RCGP_CATCHUP': '4', 'RCGP_NB': '256', 'RCGP_EXT': '2'},
+                                 {'RCGP_CATCHUP': '6', 'RCGP_NB': '384', 'RCGP_EXT': '1'}, {'RCGP_CATCHUP': '9', 'RCGP_NB': '512', 'RCGP_EXT': '3', 'RCGP_DEPTH': '1'}])
 def test_tuning_knobs_do_not_change_results(gpu, env, monkeypatch):
     """Every run-time variant (register-sweep diagonal kernel, sequential Cholesky, no reserved CUs, overlapped inverse, coarse
     panel chain, other panel widths / window depths / chain extensions of the fine-grained Cholesky) is the same arithmetic up to
@@ -357,7 +359,9 @@ def test_tuning_knobs_do_not_change_results(gpu, env, monkeypatch):
     gp.close()
 
 
-@pytest.mark.parametrize('env', [{}, {'RCGP_NB': '256', 'RCGP_DEPTH': '3'}, {'RCGP_EXT': '1', 'RCGP_DEPTH': '12'}])
+@pytest.mark.parametrize('env', [{}, {'RCGP_NB': '256', 'RCGP_DEPTH': '3'}, {'RCGP_EXT': '1', 'RCGP_DEPTH': '12'}, {'RCGP_CATCHUP': '4'},
+                                 {'RCGP_CATCHUP': '8', 'RCGP_NB': '256', 'RCGP_DEPTH': '3'}, {'RCGP_CATCHUP': '5', 'RCGP_NB': '512', 'RCGP_EXT': '3'},
+                                 {'RCGP_CATCHUP': '12', 'RCGP_NB': '384', 'RCGP_EXT': '2', 'RCGP_DEPTH': '1'}])
 def test_fine_grained_cholesky_factor_many_panels(gpu, env, monkeypatch):
     """The four-stream Cholesky (diagonal chain, column work, window pieces, bulk update) over 7+ outer panels with a ragged last
     one: the factor itself, entry by entry, against LAPACK on the oracle's Gram matrix, and w = L^-1 y through the LML."""
