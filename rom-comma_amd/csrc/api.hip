@@ -37,6 +37,7 @@ RC_API int rcgp_device_count(void) {
 // ---------------------------------------------------------------------------------------------------------------------
 struct RcDeviceStreams {
   hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr, stream5 = nullptr, stream6 = nullptr;
+  std::vector<hipStream_t> pads;       // RCGP_STREAM_PAD experiment
   int refs = 0;
 };
 static std::mutex g_streams_mutex;
@@ -62,6 +63,8 @@ static void destroy_stream_sets() {
       if (*sp) (void)hipStreamSynchronize(*sp);
     for (auto sp : all)
       if (*sp) { (void)hipStreamDestroy(*sp); *sp = nullptr; }
+    for (auto p : ds.pads) (void)hipStreamDestroy(p);
+    ds.pads.clear();
   }
 }
 
@@ -128,61 +131,86 @@ static int upload_targets(rcgp_handle_s* h, const double* Y) {
   return 0;
 }
 
+// The six streams of a device. How the runtime places them on hardware queues depends on the ORDER in which they are created and on
+// every other stream the process has made before and between them ("stream placement": 32.7 ms to 75 ms for the same
+// C2 factorisation), so the order is fixed here and two diagnostic knobs can change it: RCGP_STREAM_ORDER (the digits of the streams in
+// creation order, default "025634" = main, chain, column work, far updates, bulk, spare; leaving out 4 leaves the spare stream out) and
+// RCGP_STREAM_PAD (a:b:c:d:e:f = idle streams created before the 1st ... 6th of them).
 static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
   // RCGP_LOWPRIO: 1 = the bulk-update stream at the LOWEST priority, 2 = the main stream (window pieces) as well
   int lowprio = 0;
   if (const char* e = getenv("RCGP_LOWPRIO")) lowprio = atoi(e);
   int lo = 0, hi = 0;
   RC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));            // hi is the numerically lowest = highest priority
-  if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] stream priorities: least %d, greatest %d\n", lo, hi);
-  if (lowprio >= 2)
-    RC_HIP(hipStreamCreateWithPriority(&ds.stream, hipStreamNonBlocking, lo));
-  else
-    RC_HIP(hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking));
-  {
-    RC_HIP(hipStreamCreateWithPriority(&ds.stream2, hipStreamNonBlocking, hi));
-    RC_HIP(hipStreamCreateWithPriority(&ds.stream5, hipStreamNonBlocking, hi));
-    RC_HIP(hipStreamCreateWithPriority(&ds.stream6, hipStreamNonBlocking, hi));
-  }
-  {
-    // The bulk-update stream may be confined to every CU except the first RCGP_RESERVE_CUS, which then stay free for the panel chain.
-    // Default 0 = no mask: with the chain kernels of this build a reserve no longer pays at C2 (33.5 vs 33.4 ms with 24 CUs held back)
-    // and costs 2.4 % at N = 28672 (142.3 vs 138.9 ms), and a process without CU-masked queues cannot run into the slow regime that
-    // two active ones cause.
-    int reserve = RC_RESERVE_CUS_DEFAULT;
-    if (const char* e = getenv("RCGP_RESERVE_CUS")) reserve = atoi(e);
-    hipDeviceProp_t prop;
-    RC_HIP(hipGetDeviceProperties(&prop, h->device));
-    const int ncu = prop.multiProcessorCount;
-    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-    for (int cu = 0; cu < ncu; ++cu)
-      if (cu >= reserve) mask[cu / 32] |= (1u << (cu % 32));
-    const bool want4 = true;      // (the stream of the rejected L^-1 overlap mode: created with the others, as in every measured build)
-    hipError_t me = hipErrorInvalidValue;
-    if (reserve > 0 && reserve < ncu) me = hipExtStreamCreateWithCUMask(&ds.stream3, (uint32_t)mask.size(), mask.data());
-    if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] %d CUs, reserve %d, CU-mask stream: %s\n", ncu, reserve, hipGetErrorString(me));
-    if (me != hipSuccess) {
-      (void)hipGetLastError();
-      if (lowprio >= 1)
-        RC_HIP(hipStreamCreateWithPriority(&ds.stream3, hipStreamNonBlocking, lo));
-      else
-        RC_HIP(hipStreamCreateWithFlags(&ds.stream3, hipStreamNonBlocking));
-      if (want4) RC_HIP(hipStreamCreateWithFlags(&ds.stream4, hipStreamNonBlocking));
-    } else if (want4) {
-      // the overlapped L^-1 kernels run long tiles: confine them to the upper part of the chip so that the panel chain's GEMMs
-      // (which want many CUs at once) always find free ones
-      int reserve_inv = 128;
-      if (const char* e = getenv("RCGP_RESERVE_CUS_INV")) reserve_inv = atoi(e);
-      std::vector<uint32_t> mask4((ncu + 31) / 32, 0u);
-      for (int cu = 0; cu < ncu; ++cu)
-        if (cu >= reserve_inv) mask4[cu / 32] |= (1u << (cu % 32));
-      if (reserve_inv <= 0 || reserve_inv >= ncu ||
-          hipExtStreamCreateWithCUMask(&ds.stream4, (uint32_t)mask4.size(), mask4.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        RC_HIP(hipStreamCreateWithFlags(&ds.stream4, hipStreamNonBlocking));
-      }
+  int padn[6] = {0, 0, 0, 0, 0, 0};
+  if (const char* e = getenv("RCGP_STREAM_PAD")) sscanf(e, "%d:%d:%d:%d:%d:%d", &padn[0], &padn[1], &padn[2], &padn[3], &padn[4], &padn[5]);
+  static void* pad_word = nullptr;
+  auto pad = [&](int count, int prio) -> int {
+    for (int i = 0; i < count; ++i) {
+      hipStream_t s;
+      if (!pad_word) RC_HIP(hipMalloc(&pad_word, 64));
+      RC_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+      RC_HIP(hipMemsetAsync(pad_word, 0, 4, s));
+      RC_HIP(hipStreamSynchronize(s));
+      ds.pads.push_back(s);
     }
+    return 0;
+  };
+  // The bulk-update stream may be confined to every CU except the first RCGP_RESERVE_CUS, which then stay free for the panel chain.
+  // Default 0 = no mask: with the chain kernels of this build a reserve no longer pays at C2 (33.5 vs 33.4 ms with 24 CUs held back)
+  // and costs 2.4 % at N = 28672 (142.3 vs 138.9 ms).
+  int reserve = RC_RESERVE_CUS_DEFAULT, reserve_inv = 128;
+  if (const char* e = getenv("RCGP_RESERVE_CUS")) reserve = atoi(e);
+  if (const char* e = getenv("RCGP_RESERVE_CUS_INV")) reserve_inv = atoi(e);
+  hipDeviceProp_t prop;
+  RC_HIP(hipGetDeviceProperties(&prop, h->device));
+  const int ncu = prop.multiProcessorCount;
+  bool masked3 = false;
+  auto create_masked = [&](hipStream_t* out, int first_cu) -> bool {   // every CU from first_cu on
+    if (first_cu <= 0 || first_cu >= ncu) return false;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int cu = first_cu; cu < ncu; ++cu) mask[cu / 32] |= (1u << (cu % 32));
+    if (hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+  };
+  auto create_one = [&](char which) -> int {
+    switch (which) {
+      case '0':
+        if (lowprio >= 2) RC_HIP(hipStreamCreateWithPriority(&ds.stream, hipStreamNonBlocking, lo));
+        else RC_HIP(hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking));
+        break;
+      case '2': RC_HIP(hipStreamCreateWithPriority(&ds.stream2, hipStreamNonBlocking, hi)); break;
+      case '5': RC_HIP(hipStreamCreateWithPriority(&ds.stream5, hipStreamNonBlocking, hi)); break;
+      case '6': RC_HIP(hipStreamCreateWithPriority(&ds.stream6, hipStreamNonBlocking, hi)); break;
+      case '3':
+        masked3 = create_masked(&ds.stream3, reserve);
+        if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] %d CUs, reserve %d, CU-masked bulk stream: %s\n", ncu, reserve, masked3 ? "yes" : "no");
+        if (!masked3) {
+          if (lowprio >= 1) RC_HIP(hipStreamCreateWithPriority(&ds.stream3, hipStreamNonBlocking, lo));
+          else RC_HIP(hipStreamCreateWithFlags(&ds.stream3, hipStreamNonBlocking));
+        }
+        break;
+      case '4':
+        // (the stream of the rejected L^-1 overlap mode; beside a CU-masked bulk stream it is confined to the upper part of the chip, so
+        // that its long tiles leave CUs to the panel chain's GEMMs)
+        if (!(masked3 && create_masked(&ds.stream4, reserve_inv))) RC_HIP(hipStreamCreateWithFlags(&ds.stream4, hipStreamNonBlocking));
+        break;
+      default: return -1;
+    }
+    return 0;
+  };
+  const char* order = getenv("RCGP_STREAM_ORDER");
+  if (!order || !*order) order = "025634";
+  int k = 0;
+  for (const char* c = order; *c; ++c, ++k) {
+    const bool high = (*c == '2' || *c == '5' || *c == '6');
+    hipStream_t* slot[7] = {&ds.stream, nullptr, &ds.stream2, &ds.stream3, &ds.stream4, &ds.stream5, &ds.stream6};
+    if (*c < '0' || *c > '6' || !slot[*c - '0'] || *slot[*c - '0']) return -1;            // unknown or repeated
+    if (k < 6 && pad(padn[k], high ? hi : 0)) return -1;
+    if (create_one(*c)) return -1;
   }
+  if (!ds.stream || !ds.stream2 || !ds.stream3 || !ds.stream5 || !ds.stream6) return -1;    // only the spare stream may be left out
   return 0;
 }
 
