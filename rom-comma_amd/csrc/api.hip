@@ -166,6 +166,7 @@ static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
   RC_HIP(hipGetDeviceProperties(&prop, h->device));
   const int ncu = prop.multiProcessorCount;
   bool masked3 = false;
+  const bool reserve_all = getenv("RCGP_RESERVE_ALL") && getenv("RCGP_RESERVE_ALL")[0] != '0';
   auto create_masked = [&](hipStream_t* out, int first_cu) -> bool {   // every CU from first_cu on
     if (first_cu <= 0 || first_cu >= ncu) return false;
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
@@ -181,8 +182,14 @@ static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
         else RC_HIP(hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking));
         break;
       case '2': RC_HIP(hipStreamCreateWithPriority(&ds.stream2, hipStreamNonBlocking, hi)); break;
-      case '5': RC_HIP(hipStreamCreateWithPriority(&ds.stream5, hipStreamNonBlocking, hi)); break;
-      case '6': RC_HIP(hipStreamCreateWithPriority(&ds.stream6, hipStreamNonBlocking, hi)); break;
+      // RCGP_RESERVE_ALL=1: the column-work streams stay off the reserved CUs as well (with RCGP_PIECES_ON_BULK=1 the chain stream is then
+      // the only one that can reach them); a CU-masked stream has no priority
+      case '5':
+        if (!(reserve_all && create_masked(&ds.stream5, reserve))) RC_HIP(hipStreamCreateWithPriority(&ds.stream5, hipStreamNonBlocking, hi));
+        break;
+      case '6':
+        if (!(reserve_all && create_masked(&ds.stream6, reserve))) RC_HIP(hipStreamCreateWithPriority(&ds.stream6, hipStreamNonBlocking, hi));
+        break;
       case '3':
         masked3 = create_masked(&ds.stream3, reserve);
         if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] %d CUs, reserve %d, CU-masked bulk stream: %s\n", ncu, reserve, masked3 ? "yes" : "no");

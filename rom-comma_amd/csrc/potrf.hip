@@ -141,7 +141,7 @@ __device__ __forceinline__ void inv_steps(double (&Xr)[4][8], const double (&Lr)
   }
 }
 
-__global__ void __launch_bounds__(512, 2) k_diag(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
+__global__ void __launch_bounds__(512, 4) k_diag(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
                                                  double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
   __shared__ double colbuf[4 * 128], rowbuf[4 * 128], rsd[128], rv[128];
   __builtin_amdgcn_s_setprio(3);             // latency-critical: win issue arbitration against co-resident GEMM waves
@@ -221,12 +221,18 @@ __global__ void __launch_bounds__(512, 2) k_diag(double* __restrict__ A, int64_t
 // =====================================================================================================================
 #ifdef RC_DIAG_TIMING
 __device__ long long g_diag_t[32];
+__device__ long long g_diag_span[2 * 512];      // entry / exit stamp of the diagonal kernel of block j0 / 128
 #define RC_T(i) do { if (threadIdx.x == 0) g_diag_t[i] = wall_clock64(); } while (0)
+#define RC_SPAN(k) do { if (threadIdx.x == 0) g_diag_span[2 * ((j0 / 128) & 511) + (k)] = wall_clock64(); } while (0)
 extern "C" __attribute__((visibility("default"))) int rcgp_debug_diag_times(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_t), sizeof(long long) * 32);
 }
+extern "C" __attribute__((visibility("default"))) int rcgp_debug_diag_spans(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_span), sizeof(long long) * 2 * 512);
+}
 #else
 #define RC_T(i)
+#define RC_SPAN(k)
 #endif
 
 #define LS 130
@@ -350,6 +356,7 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
   const int fr = lane & 15, fq = lane >> 4;
   double* At = A + j0 * ld + j0;
   RC_T(0);
+  RC_SPAN(0);
   {
     // 16 bytes per lane; pairs entirely above the diagonal are not fetched. All sixteen loads of a lane are issued before the first is
     // waited for (as a loop this is sixteen memory round trips in a row: 5.5 us of the kernel on an idle chip, far more beside GEMMs).
@@ -557,6 +564,7 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
     if (h4 == 0) rhs[j0 + i] = s;
   }
   RC_T(23);
+  RC_SPAN(1);
 }
 
 template <int MODE>
