@@ -213,11 +213,17 @@ static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
   for (const char* c = order; *c; ++c, ++k) {
     const bool high = (*c == '2' || *c == '5' || *c == '6');
     hipStream_t* slot[7] = {&ds.stream, nullptr, &ds.stream2, &ds.stream3, &ds.stream4, &ds.stream5, &ds.stream6};
-    if (*c < '0' || *c > '6' || !slot[*c - '0'] || *slot[*c - '0']) return -1;            // unknown or repeated
+    if (*c < '0' || *c > '6' || !slot[*c - '0'] || *slot[*c - '0']) {                   // unknown or repeated
+      h->err = "RCGP_STREAM_ORDER: a permutation of the digits 0 2 5 6 3 (and optionally 4) is expected";
+      return -1;
+    }
     if (k < 6 && pad(padn[k], high ? hi : 0)) return -1;
     if (create_one(*c)) return -1;
   }
-  if (!ds.stream || !ds.stream2 || !ds.stream3 || !ds.stream5 || !ds.stream6) return -1;    // only the spare stream may be left out
+  if (!ds.stream || !ds.stream2 || !ds.stream3 || !ds.stream5 || !ds.stream6) {            // only the spare stream may be left out
+    h->err = "RCGP_STREAM_ORDER: only stream 4 may be left out";
+    return -1;
+  }
   return 0;
 }
 

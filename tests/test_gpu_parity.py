@@ -339,6 +339,8 @@ def test_sobol_error_terms(gpu, L):
                                  {'RCGP_DLOOP': '1'}, {'RCGP_DLOOP': '2', 'RCGP_NB': '384'}, {'RCGP_PREP_SMALL': '1'}, {'RCGP_BULK_AFTER_PIECE': '1'}, {'RCGP_T2WAIT': '1'}, {'RCGP_PIECES_ON_BULK': '1', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_PSPLIT': '3', 'RCGP_SHORTK': '0', 'RCGP_NB': '256'}, {'RCGP_SPLIT': '0', 'RCGP_EXT': '2', 'RCGP_DEPTH': '4'},
                                  {'RCGP_EXT': '2'}, {'RCGP_EXT': '6', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_PSPLIT': '0'}, {'RCGP_PSPLIT': '1'},
                                  {'RCGP_CATCHUP': '4'}, {'RCGP_CATCHUP': '4', 'RCGP_NB': '256', 'RCGP_EXT': '2'},
+                                 {'RCGP_RESERVE_CUS': '8', 'RCGP_RESERVE_ALL': '1', 'RCGP_PIECES_ON_BULK': '1'},
+                                 {'RCGP_RESERVE_CUS': '24', 'RCGP_STREAM_ORDER': '352604'}, {'RCGP_DIAG': '1', 'RCGP_PREP_SMALL': '1', 'RCGP_SHORTK': '0'},
                                  {'RCGP_CATCHUP': '6', 'RCGP_NB': '384', 'RCGP_EXT': '1'}, {'RCGP_CATCHUP': '9', 'RCGP_NB': '512', 'RCGP_EXT': '3', 'RCGP_DEPTH': '1'}])
 def test_tuning_knobs_do_not_change_results(gpu, env, monkeypatch):
     """Every run-time variant (register-sweep diagonal kernel, sequential Cholesky, no reserved CUs, overlapped inverse, coarse
