@@ -3,6 +3,7 @@
     python tools/collect_profiles.py r01b r01
 """
 import glob
+import os
 import shutil
 import subprocess
 import sys
@@ -15,7 +16,7 @@ dst = ROOT / 'profiles'
 
 
 def one(pattern):
-    return glob.glob(str(src / pattern))[0]
+    return max(glob.glob(str(src / pattern)), key=os.path.getmtime)      # (an earlier run's files may lie beside it)
 
 
 shutil.copy(one('bench/*/*_kernel_stats.csv'), dst / f'{name}_bench_c2_kernel_stats.csv')

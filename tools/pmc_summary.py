@@ -8,6 +8,7 @@ side is doubled; WRITE_SIZE is exact for 16-B-per-lane stores. Units: FETCH_SIZE
 import collections
 import csv
 import glob
+import os
 import json
 import sys
 
@@ -15,7 +16,8 @@ GEMM = ('k_syrk_lower', 'k_gemm_nt_sub', 'k_trsm_panel', 'k_prep_next', 'k_trtri
 
 
 def rows(folder, name):
-    return list(csv.DictReader(open(glob.glob(f'{folder}/*/*_{name}.csv')[0])))
+    newest = max(glob.glob(f'{folder}/*/*_{name}.csv'), key=os.path.getmtime)       # (an earlier run's files may lie beside it)
+    return list(csv.DictReader(open(newest)))
 
 
 def short(kernel_name):
