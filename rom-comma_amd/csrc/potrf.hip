@@ -718,7 +718,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
   RC_HIP(hipEventRecord(e0, h->stream));
   RC_HIP(hipStreamWaitEvent(C, e0, 0));
   RC_HIP(hipStreamWaitEvent(B, e0, 0));
-  hipEvent_t eG_prev = nullptr, eU1_prev = nullptr, eU2_prev = nullptr, eFar_prev = nullptr;
+  hipEvent_t eG_prev = nullptr, eU1_prev = nullptr, eU2_prev = nullptr, eFar_prev = nullptr, eCU_prev1 = nullptr, eCU_prev2 = nullptr;
   hipStream_t B2 = h->stream6;
   RC_HIP(hipStreamWaitEvent(B2, e0, 0));
   bool near_waited = false, far_waited = false;                  // this panel's wait for the previous panel's window piece
@@ -820,26 +820,45 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
       if ((rc = rc_launch_trsm_panel(h, P + 128 * Np, Np, inv, below - 128, h->w + j + 256, h->w + j)) || (rc = flush_stop(h))) return rc;
       if (!ext) RC_HIP(hipEventRecord(eT2, B));
       const int64_t c0 = j + 128, nend = (c0 + 256 < cend) ? c0 + 256 : cend;
+      // Catch-up mode (RCGP_CATCHUP = t, off by default) for the block columns taller than t blocks: instead of a K=128 far update at
+      // every step -- one read-modify-write of the whole column per step, which is what makes the column work HBM-heavy -- a column c
+      // receives ONE update with every finished column its window pieces do not deliver, [lo(c), c - 3 blocks), when it is four blocks
+      // ahead of the chain (far stream; two steps of slack before anything waits for it), then the steps c-3 and c-2 together (K=256)
+      // when it enters the near window as its second column, then step c-1 (K=128) as its first column: three passes instead of
+      // ~EXT + NB/128. Panel q reaches column c through its window pieces iff c >= (q + 1) NB + EXT, so lo(c) = floor((c - EXT)/NB) NB;
+      // EXT >= 3 blocks keeps the two steps of the K=256 update on the chain's side of that boundary.
+      const int64_t ccut = (h->catchup_blocks > 0 && h->chain_ext >= 3 && Np > 128 * (int64_t)h->catchup_blocks)
+                               ? Np - 128 * (int64_t)h->catchup_blocks : 0;
+      const int64_t c2 = c0 + 128;                               // second near column
+      const bool c2_catchup = (nend - c0 == 256 && c2 < ccut && j >= 128);
       RC_HIP(hipStreamWaitEvent(B, eP, 0));
-      if (eFar_prev) RC_HIP(hipStreamWaitEvent(B, eFar_prev, 0));
+      if (c2_catchup) {
+        if (eCU_prev2) RC_HIP(hipStreamWaitEvent(B, eCU_prev2, 0));   // the catch-up of column c2 was issued two steps ago
+      } else if (eFar_prev) {
+        RC_HIP(hipStreamWaitEvent(B, eFar_prev, 0));
+      }
       if (have_win && !near_waited && nend > u0_prev) { RC_HIP(wait_window(B)); near_waited = true; }
-      if (ext) h->launch_stop = eG;
-      if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + c0, Np, P + 128 * Np, Np, P, Np, below - 128, nend - c0, 128, j + 256, c0)) ||
-          (rc = flush_stop(h)))
-        return rc;
+      if (c2_catchup) {
+        if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + c0, Np, P + 128 * Np, Np, P, Np, below - 128, 128, 128, j + 256, c0))) return rc;
+        if (ext) h->launch_stop = eG;
+        if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + c2, Np, h->A + (j + 256) * Np + (j - 128), Np, h->A + c2 * Np + (j - 128), Np,
+                                        below - 128, 128, 256, j + 256, c2)) ||
+            (rc = flush_stop(h)))
+          return rc;
+      } else {
+        if (ext) h->launch_stop = eG;
+        if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + c0, Np, P + 128 * Np, Np, P, Np, below - 128, nend - c0, 128, j + 256, c0)) ||
+            (rc = flush_stop(h)))
+          return rc;
+      }
       if (!ext) RC_HIP(hipEventRecord(eG, B));
-      // Beyond the near columns: either the K=128 update of all of [nend, cend) at every step (far G), or -- for the block columns
-      // taller than catchup_blocks -- nothing until the column is three blocks ahead, then ONE update with every finished column its
-      // window pieces do not deliver, [lo, j + 128): the same flops with one read-modify-write of the column instead of one per
-      // step (K up to NB + 128 instead of 128). Panel q reaches column cc through its pieces iff cc >= (q + 1) NB + EXT.
-      const int64_t ccut = (h->catchup_blocks > 0 && Np > 128 * (int64_t)h->catchup_blocks) ? Np - 128 * (int64_t)h->catchup_blocks : 0;
-      const int64_t cc = c0 + 256;                               // the column that joins the near window at the next step
+      const int64_t cc = c0 + 384;                               // the column four blocks ahead
       const int64_t lo = ((cc >= EXT) ? (cc - EXT) / NB : 0) * NB;
       const bool do_cu = (cc < cend && cc < ccut && j + 128 > lo);
       const int64_t f0 = (nend > ccut) ? nend : ccut;
       const bool do_far = (cend > f0);
+      hipEvent_t eCU = nullptr;
       if (do_cu || do_far) {
-        if ((rc = next_event(h, &eFar))) return rc;
         RC_HIP(hipStreamWaitEvent(B2, eT2, 0));
         if (have_win && !far_waited && ((do_far && cend > u0_prev) || (do_cu && cc + 128 > u0_prev))) {
           RC_HIP(wait_window(B2));
@@ -847,22 +866,27 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
         }
         h->launch = B2;
         if (do_cu) {
-          if (ext && !do_far) h->launch_stop = eFar;
+          if ((rc = next_event(h, &eCU))) return rc;
+          if (ext) h->launch_stop = eCU;
           if ((rc = rc_launch_gemm_nt_sub(h, h->A + cc * Np + cc, Np, h->A + cc * Np + lo, Np, h->A + cc * Np + lo, Np, Np - cc, 128,
                                           j + 128 - lo, cc, cc)) ||
               (rc = flush_stop(h)))
             return rc;
+          if (!ext) RC_HIP(hipEventRecord(eCU, B2));
         }
         if (do_far) {
+          if ((rc = next_event(h, &eFar))) return rc;
           if (ext) h->launch_stop = eFar;
           if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + f0, Np, P + 128 * Np, Np, P + (f0 - c0) * Np, Np, below - 128, cend - f0, 128,
                                           j + 256, f0)) ||
               (rc = flush_stop(h)))
             return rc;
+          if (!ext) RC_HIP(hipEventRecord(eFar, B2));
+          eFar_prev = eFar;
         }
-        if (!ext) RC_HIP(hipEventRecord(eFar, B2));
-        eFar_prev = eFar;
       }
+      eCU_prev2 = eCU_prev1;
+      eCU_prev1 = eCU;
       if (j + 128 == pend) {                                      // the outer updates need both halves
         if ((rc = next_event(h, &ePanel))) return rc;
         if (eFar_prev) RC_HIP(hipStreamWaitEvent(B, eFar_prev, 0));
