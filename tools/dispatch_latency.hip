@@ -13,7 +13,11 @@
 #define CK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(err_)); return 1; } } while (0)
 
 __global__ void __launch_bounds__(512, 2) k_hog(int ticks, double* sink, int jitter) {
-  if (jitter) ticks += (ticks * (int)(blockIdx.x % 8)) / 16;  // tiles of unequal length: up to +44 %
+  if (jitter == 1) ticks += (ticks * (int)(blockIdx.x % 8)) / 16;  // tiles of unequal length: up to +44 %
+  if (jitter == 2 && blockIdx.x < 512) {                          // equal tiles, first generation staggered over one tile time
+    const long long until = wall_clock64() + (long long)((blockIdx.x * 37u) & 63u) * ticks / 64;
+    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+  }
   __shared__ double pad[8192];                               // 64 KB: two workgroups per CU
   asm volatile("v_mov_b32 v127, 0" ::: "v127");             // 128 VGPRs: two workgroups fill the register file as well
   pad[threadIdx.x] = (double)threadIdx.x;
