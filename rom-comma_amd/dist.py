@@ -18,8 +18,18 @@ def env_rank_world() -> Tuple[int, int, int]:
     return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
 
 
+def prepare_environment():
+    """Environment defaults that must be in place BEFORE the first GPU call of the process (ROCr reads HSA_* once, at hsa_init):
+    ``HSA_ENABLE_IPC_MODE_LEGACY=0`` selects dmabuf IPC handles, the only kind the host driver of the target MI355X nodes supports --
+    with the legacy mode RCCL's (and torch's) cross-process buffer sharing on one node fails with ``hipIpcGetMemHandle: invalid
+    argument`` (stated by the platform notes of the build; the GPU boxes export the variable themselves). ``setdefault``: an explicit
+    setting in the caller's environment wins. Called at ``romcomma_amd`` import and again at the top of ``init_process_group``."""
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+
 def init_process_group(backend: str | None = None):
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    prepare_environment()                                     # before torch.cuda is touched below
     import torch
     import torch.distributed as dist
     rank, world, local_rank = env_rank_world()
@@ -28,7 +38,6 @@ def init_process_group(backend: str | None = None):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # (the host driver supports dmabuf IPC only)
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
@@ -98,6 +107,16 @@ def all_gather_rows(local: np.ndarray, n_units: int, unit_ids: Sequence[int]) ->
     return out
 
 
+def broadcast_object(obj, src: int = 0):
+    """A small picklable object from rank ``src`` to every rank (host-side metadata: fold lists, shapes)."""
+    import torch.distributed as dist
+    if not is_distributed():
+        return obj
+    box = [obj if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src, device=_device())
+    return box[0]
+
+
 def max_over_ranks(value: float) -> float:
     import torch
     import torch.distributed as dist
@@ -109,7 +128,7 @@ def max_over_ranks(value: float) -> float:
 
 
 
-def agree_on_failure(error: BaseException | None) -> None:
+def agree_on_failure(error: Exception | None) -> None:
     """Called by every rank after its share of a sharded loop, with the exception it caught (or None). If ANY rank failed, every
     rank raises -- the failing ones their own exception, the others a RuntimeError naming the ranks -- so that nobody is left
     waiting in the next collective for a rank that has gone (the reference's loop is sequential and simply propagates,

@@ -1,10 +1,14 @@
-"""GSA driver (reference gsa/models.py:35-214): builds the dimension slices of each kind, asks the calibrator for each,
-post-processes (total = full - closed-of-complement), writes S.csv / V.csv with the reference's index and column labels."""
-from __future__ import annotations
+"""GSA driver (interface: reference gsa/models.py:35-214). A ``Sobol`` calculation of one kind asks its calibrator for the conditional
+variance of every input slice of that kind, turns them into indices, and writes ``S.csv`` / ``V.csv`` (``T.csv`` / ``W.csv`` with errors)
+under ``<gp folder>/gsa/<kind>[.<m>]`` with the reference's row index (l.0, l.1) and column labels m.
 
+Slices per kind, 0-based half-open [lo, hi) over the M input dimensions (gsa/models.py:77-90):
+    FIRST_ORDER  [m, m+1)      CLOSED  [0, m+1)      TOTAL  [m+1, M)  -- the COMPLEMENT, from which total = S_full - S_closed(complement)
+Every stored table gets one more column, labelled M, holding the full-model value (gsa/models.py:49-63, 207-214).
+"""
+import enum
 from abc import abstractmethod
-from enum import IntEnum, auto
-from typing import Any, Dict, List, NamedTuple
+from typing import Any, Callable, NamedTuple
 
 import numpy as np
 import pandas as pd
@@ -16,59 +20,64 @@ from romcomma_amd.gsa.calibrators import ClosedSobol, ClosedSobolWithError
 
 
 class GSA(Model):
-    """A generic sensitivity calculation on a fitted GP."""
+    """A sensitivity calculation on a fitted GP: slices -> calibrator -> tables."""
 
-    class Kind(IntEnum):
-        FIRST_ORDER = auto()
-        CLOSED = auto()
-        TOTAL = auto()
+    class Kind(enum.IntEnum):
+        FIRST_ORDER = 1
+        CLOSED = 2
+        TOTAL = 3
 
     @classmethod
     @property
-    def ALL_KINDS(cls) -> List['GSA.Kind']:
-        return [kind for kind in cls.Kind]
+    def ALL_KINDS(cls) -> list['GSA.Kind']:
+        return list(cls.Kind)
+
+    _SLICE_OF: dict[int, Callable[[int, int], tuple[int, int]]] = {
+        1: lambda m, M: (m, m + 1),
+        2: lambda m, M: (0, m + 1),
+        3: lambda m, M: (m + 1, M),
+    }
 
     def __init__(self, gp: GPR, kind: 'GSA.Kind', m: int = -1, is_error_calculated: bool = False, **kwargs: Any):
-        """Results go to ``gp.folder / 'gsa' / <kind>[.m]``; ``m`` outside [0, M) means every m (gsa/models.py:139-160)."""
-        self.gp = gp
-        self.is_error_calculated = is_error_calculated
-        self.kind = kind
-        m = m if 0 <= m < gp.M else -1
-        name = kind.name.lower() if m == -1 else f'{kind.name.lower()}.{m}'
-        folder = gp.folder / 'gsa' / name
-        super().__init__(folder, read_data=False)
-        self.meta = {'folder': str(folder), 'm': m, 'M': gp.M} | self.META | kwargs
+        """``m`` in [0, M) restricts the calculation to that input and appends ``.m`` to the folder name; anything else means all inputs
+        and is recorded as -1 (gsa/models.py:139-160)."""
+        self.gp, self.kind, self.is_error_calculated = gp, kind, is_error_calculated
+        one_input = 0 <= m < gp.M
+        label = f'{kind.name.lower()}.{m}' if one_input else kind.name.lower()
+        where = gp.folder / 'gsa' / label
+        super().__init__(where, read_data=False)
+        self.meta = {'folder': str(where), 'm': m if one_input else -1, 'M': gp.M, **self.META, **kwargs}
         self.write_meta(self.meta)
 
-    @staticmethod
-    def _columns(M: int, m_cols: int, m_list: List[int]) -> pd.Index:
-        """Column labels m = 0..M-1 plus M for the appended full-model column (gsa/models.py:49-63)."""
-        if m_cols > len(m_list):
-            m_list = m_list + [M]
-        if m_cols > len(m_list):
-            m_list = [-1] + m_list
-        return pd.Index(m_list, name='m')
+    @property
+    def _inputs(self) -> list[int]:
+        """The input dimensions this calculation covers."""
+        return [self.meta['m']] if self.meta['m'] >= 0 else list(range(self.meta['M']))
 
     @staticmethod
-    def _index(shape: List[int]) -> pd.MultiIndex:
-        """Row MultiIndex (l.0, l.1) over the leading (L, L) axes (gsa/models.py:65-75)."""
-        ranges = [list(range(n)) for n in shape[:-1]]
-        return pd.MultiIndex.from_product(ranges, names=[f'l.{i}' for i in range(len(ranges))])
+    def _columns(M: int, m_cols: int, m_list: list[int]) -> pd.Index:
+        """Column labels for a table with ``m_cols`` columns: the inputs in ``m_list``, then M for the full-model column if there is
+        room for it, then a leading -1 if there is still a column unaccounted for."""
+        labels = list(m_list)
+        if len(labels) < m_cols:
+            labels.append(M)
+        if len(labels) < m_cols:
+            labels.insert(0, -1)
+        return pd.Index(labels, name='m')
+
+    @staticmethod
+    def _index(shape: list[int]) -> pd.MultiIndex:
+        """Row labels (l.0, l.1, ...) enumerating every axis of ``shape`` but the last."""
+        axes = [range(extent) for extent in shape[:-1]]
+        return pd.MultiIndex.from_product(axes, names=[f'l.{position}' for position in range(len(axes))])
 
     @property
-    def _m_dataset(self) -> List[np.ndarray]:
-        """One int32 pair per marginalisation: FIRST_ORDER [m, m+1), CLOSED [0, m+1), TOTAL [m+1, M) (gsa/models.py:77-90)."""
-        m, M = self.meta['m'], self.meta['M']
-        ms = range(M) if m < 0 else [m]
-        if self.kind == GSA.Kind.FIRST_ORDER:
-            pairs = [(i, i + 1) for i in ms]
-        elif self.kind == GSA.Kind.CLOSED:
-            pairs = [(0, i + 1) for i in ms]
-        elif self.kind == GSA.Kind.TOTAL:
-            pairs = [(i + 1, M) for i in ms]
-        else:
-            pairs = []
-        return [np.array(p, dtype=np.int32) for p in pairs]
+    def _m_dataset(self) -> list[np.ndarray]:
+        """The int32 [lo, hi) pair of every slice of this kind, in input order."""
+        slice_of = self._SLICE_OF.get(int(self.kind))
+        if slice_of is None:
+            return []
+        return [np.asarray(slice_of(i, self.meta['M']), dtype=np.int32) for i in self._inputs]
 
     @property
     @abstractmethod
@@ -76,74 +85,79 @@ class GSA(Model):
         raise NotImplementedError
 
     @abstractmethod
-    def _post_calibrate(self, calibrator: Calibrator, results: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    def _post_calibrate(self, calibrator: Calibrator, results: dict[str, np.ndarray]) -> dict[str, np.ndarray]:
         raise NotImplementedError
 
-    def _compose_and_save(self, results: Dict[str, np.ndarray]):
-        """Each result (L, L, columns) flattened to rows (l.0, l.1), written with float_format '%.6f' (gsa/models.py:102-115)."""
-        m, M = self.meta['m'], self.meta['M']
-        m_list = list(range(M)) if m < 0 else [m]
-        for key, frame in self.data.asdict().items():
-            result = results.get(key, None)
-            if result is not None:
-                shape = list(result.shape)
-                table = pd.DataFrame(np.reshape(result, (-1, shape[-1])), columns=GSA._columns(M, shape[-1], m_list), index=GSA._index(shape))
-                Frame(frame.csv, table, float_format='%.6f')
+    def _compose_and_save(self, results: dict[str, np.ndarray]):
+        """Each available table (L, L, columns) goes to its csv as rows (l.0, l.1), six decimals (gsa/models.py:102-115)."""
+        M = self.meta['M']
+        for name, frame in self.data.asdict().items():
+            if results.get(name) is None:
+                continue
+            table = np.asarray(results[name])
+            rows = table.reshape(-1, table.shape[-1])
+            labelled = pd.DataFrame(rows, index=self._index(list(table.shape)), columns=self._columns(M, table.shape[-1], self._inputs))
+            Frame(frame.csv, labelled, float_format='%.6f')
 
-    def calibrate(self, method: str = None, **kwargs) -> Dict[str, Any]:
-        """Marginalise every slice, stack on a new last axis, post-process, save (gsa/models.py:117-137)."""
+    def calibrate(self, method: str = None, **kwargs) -> dict[str, Any]:
+        """Run every slice through the calibrator, stack per key along a new last axis, post-process, store. The unrounded tables stay
+        in ``self.results`` (the csv files are rounded)."""
         calibrator = self.calibrator
-        results: Dict[str, np.ndarray] = {}
-        for m in self._m_dataset:
-            for key, value in calibrator.marginalize(m).items():
-                value = np.asarray(value)[..., None]
-                results[key] = value if key not in results else np.concatenate([results[key], value], axis=-1)
-        results = self._post_calibrate(calibrator, results)
-        self.results = results          # in-memory values (the csv files are rounded to 6 decimals)
-        self._compose_and_save(results)
+        per_key: dict[str, list[np.ndarray]] = {}
+        for pair in self._m_dataset:
+            for key, value in calibrator.marginalize(pair).items():
+                per_key.setdefault(key, []).append(np.asarray(value))
+        stacked = {key: np.stack(values, axis=-1) for key, values in per_key.items()}
+        self.results = self._post_calibrate(calibrator, stacked)
+        self._compose_and_save(self.results)
         return self.meta
 
 
 class Sobol(GSA):
-    """Sobol indices S (and conditional variances V) of one kind."""
+    """Sobol indices S with the conditional variances V behind them, optionally their standard errors T and the covariances W."""
 
     class Data(Data):
         class NamedTuple(NamedTuple):
-            S: Any = np.atleast_2d(None)       # the Sobol index
-            T: Any = np.atleast_2d(None)       # its standard deviation (with errors only)
-            V: Any = np.atleast_2d(None)       # the conditional variances behind S
-            W: Any = np.atleast_2d(None)       # the covariances behind T (with errors only)
+            S: Any = np.atleast_2d(None)
+            T: Any = np.atleast_2d(None)
+            V: Any = np.atleast_2d(None)
+            W: Any = np.atleast_2d(None)
 
     @classmethod
     @property
-    def META(cls) -> Dict[str, Any]:
+    def META(cls) -> dict[str, Any]:
         return ClosedSobolWithError.META
+
+    def _gp_signature(self) -> tuple:
+        """Changes whenever the gp's parameters do: keys the calibrator cache."""
+        if hasattr(self.gp, 'hyper_signature'):                          # an OutputShard (outputs on different ranks)
+            return self.gp.hyper_signature()
+        kernel, likelihood = self.gp.kernel.data.frames, self.gp.likelihood.data.frames
+        return tuple(np.concatenate([np.ravel(kernel.lengthscales.np), np.ravel(kernel.variance.np), np.ravel(likelihood.variance.np)]))
 
     @property
     def calibrator(self) -> ClosedSobol:
-        meta = {k: v for k, v in self.meta.items()}
+        options = dict(self.meta)
         if self.is_error_calculated:
-            return ClosedSobolWithError(self.gp, **meta)
-        # The three kinds of one gp share every conditional variance: reuse the calibrator while the hyper-parameters stand.
-        if hasattr(self.gp, 'hyper_signature'):            # an OutputShard (outputs on different ranks)
-            signature = self.gp.hyper_signature()
-        else:
-            signature = tuple(np.concatenate([np.ravel(self.gp.kernel.data.frames.lengthscales.np), np.ravel(self.gp.kernel.data.frames.variance.np),
-                                              np.ravel(self.gp.likelihood.data.frames.variance.np)]))
-        cached = getattr(self.gp, '_closed_sobol', None)
-        if cached is None or cached[0] != signature:
-            cached = (signature, ClosedSobol(self.gp, **meta))
-            self.gp._closed_sobol = cached
-        return cached[1]
+            return ClosedSobolWithError(self.gp, **options)
+        # first-order, closed and total of one gp read the same conditional variances: one calibrator serves all three
+        signature, held = self._gp_signature(), getattr(self.gp, '_closed_sobol', None)
+        if held is None or held[0] != signature:
+            held = (signature, ClosedSobol(self.gp, **options))
+            self.gp._closed_sobol = held
+        return held[1]
 
-    def _post_calibrate(self, calibrator: ClosedSobol, results: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
-        """Append the full-model column; TOTAL index = S_full - S_closed(complement) (gsa/models.py:207-214)."""
-        results['V'] = np.concatenate([results['V'], calibrator.V[0][..., None]], axis=-1)
-        if self.kind == GSA.Kind.TOTAL:
-            results['S'] = calibrator.S[..., None] - results['S']
-        results['S'] = np.concatenate([results['S'], calibrator.S[..., None]], axis=-1)
+    def _post_calibrate(self, calibrator: ClosedSobol, results: dict[str, np.ndarray]) -> dict[str, np.ndarray]:
+        """Append the full-model column to V, S (and T when complete errors were asked for); a TOTAL calculation first turns the
+        complement's closed index into the total index (gsa/models.py:207-214)."""
+        def with_full(table: np.ndarray, full: np.ndarray) -> np.ndarray:
+            return np.concatenate([table, full[..., None]], axis=-1)
+
+        is_total = self.kind == GSA.Kind.TOTAL
+        results['V'] = with_full(results['V'], calibrator.V[0])
+        S = calibrator.S[..., None] - results['S'] if is_total else results['S']
+        results['S'] = with_full(S, calibrator.S)
         if 'T' in results and not self.meta['is_T_partial']:
-            if self.kind == GSA.Kind.TOTAL:
-                results['T'] = calibrator.T[..., None] + results['T']
-            results['T'] = np.concatenate([results['T'], calibrator.T[..., None]], axis=-1)
+            T = calibrator.T[..., None] + results['T'] if is_total else results['T']
+            results['T'] = with_full(T, calibrator.T)
         return results

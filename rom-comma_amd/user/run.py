@@ -1,16 +1,25 @@
-"""Orchestration of GPR and GSA over the folds of a Repository (reference user/run.py:35-158), with the one structural
-change that suits 8 GPUs: the sequential ``for k in repo.folds`` loop (user/run.py:60-61,132-133) becomes a round-robin
-shard over the ranks of a ``torch.distributed`` job (one process per GPU). Folds are independent, so there is no data-path
-collective; ranks write their fold folders to the shared file system, meet at a barrier, and rank 0 runs the same
-``results.Collect`` pass the reference runs. Single-process use is unchanged.
+"""``gpr`` / ``gsa`` over a Fold or over all folds of a Repository -- the two user-level entry points of the reference
+(interface: user/run.py:35-158) -- plus the sharded forms this backend adds for a one-process-per-GPU job.
 
-Naming, the isotropic -> anisotropic warm start by folder copy, per-fold Timer and ``ignore_exceptions`` follow the reference.
+Organisation (own, not the reference's recursion): the ``None`` options ("do both") are expanded ONCE into an ordered plan of
+``_Variant`` records (``_plan``); a fold is then simply walked through the plan. What the plan encodes:
+
+    is_covariant None  ->  the independent model first, then the covariant one warm-started (start=None), anisotropic unless told otherwise
+    is_isotropic None  ->  the isotropic model first, then the anisotropic one warm-started
+    start None (warm)  ->  resume the model's own folder if it exists; else copy the nearest stored relative -- for a covariant model the
+                           independent model of the same isotropy, otherwise / failing that the isotropic model of the same covariance -- and
+                           resume from the copy; with no relative on disk, start fresh
+    model folder name  ->  <name>.<c|v>.<i|a>
+
+Folds are independent, so across a Repository they are dealt round-robin to the ranks of a ``torch.distributed`` job (no data-path
+collective); ranks meet at a barrier and rank 0 concatenates the per-fold csv files exactly as a single process does
+(``results.Collect``, user/results.py:98-114). Failure handling in a job: every rank reports after its share (``dist.agree_on_failure``)
+and all raise together; only ``Exception`` is caught for that -- KeyboardInterrupt / SystemExit end the rank at once.
 """
-from __future__ import annotations
-
 import shutil
+from dataclasses import dataclass
 from pathlib import Path
-from typing import Any, List, Optional, Sequence
+from typing import Any, Callable, Optional, Sequence
 
 import numpy as np
 
@@ -22,101 +31,127 @@ from romcomma_amd.gsa.models import GSA, Sobol
 from romcomma_amd.user import contexts, results
 
 
-def _my_folds(repo: Repository, shard_folds: bool = True) -> List[int]:
+@dataclass(frozen=True)
+class _Variant:
+    """One model of the plan. ``start``: True = resume the stored model, False = fresh parameters, None = warm start (module docstring)."""
+    covariant: bool
+    isotropic: bool
+    start: Optional[bool] = True
+
+    def model_name(self, name: str) -> str:
+        return f'{name}.{"c" if self.covariant else "v"}.{"i" if self.isotropic else "a"}'
+
+    def relatives(self, name: str) -> list[str]:
+        """Stored models a warm start may copy from, nearest first."""
+        same_isotropy_independent = [_Variant(False, self.isotropic).model_name(name)] if self.covariant else []
+        return same_isotropy_independent + [_Variant(self.covariant, True).model_name(name)]
+
+
+def _plan(start: Optional[bool], is_covariant: Optional[bool], is_isotropic: Optional[bool]) -> list[_Variant]:
+    if is_covariant is None:
+        covariances = [(False, start, is_isotropic), (True, None, False if is_isotropic is None else is_isotropic)]
+    else:
+        covariances = [(is_covariant, start, is_isotropic)]
+    plan = []
+    for covariant, first_start, isotropic in covariances:
+        if isotropic is None:
+            plan += [_Variant(covariant, True, first_start), _Variant(covariant, False, None)]
+        else:
+            plan.append(_Variant(covariant, isotropic, first_start))
+    return plan
+
+
+def _resolve_warm_start(fold: Fold, name: str, variant: _Variant) -> bool:
+    """Decide a ``start=None`` variant on this fold: True (resume, possibly from a relative just copied into place) or False (fresh)."""
+    own = fold.folder / variant.model_name(name)
+    if own.exists():
+        return True
+    for relative in variant.relatives(name):
+        if (fold.folder / relative).exists() and fold.folder / relative != own:
+            GPR.Data.copy(src_folder=fold.folder / relative, dst_folder=own)
+            return True
+    return False
+
+
+def _my_folds(repo: Repository, shard_folds: bool = True) -> list[int]:
     rank, world, _ = dist.env_rank_world()
-    folds = list(repo.folds)
-    return [folds[i] for i in dist.shard_units(len(folds), rank, world)] if (world > 1 and shard_folds) else folds
+    every = list(repo.folds)
+    return [every[i] for i in dist.shard_units(len(every), rank, world)] if (world > 1 and shard_folds) else every
 
 
-def _over_folds(repo: Repository, shard_folds: bool, one_fold):
-    """Run ``one_fold(Fold)`` over this rank's folds. In a distributed job a rank that fails must not leave the others waiting in the
-    barrier that follows (they would sit there until the RCCL timeout): every rank reports, and all of them raise together."""
-    result, error = [], None
+def _each_fold(repo: Repository, shard_folds: bool, job: Callable[[Fold], list]) -> list:
+    """``job(Fold)`` on this rank's folds; returns the last result. Sharded: all ranks agree on success before anyone goes on to the
+    barrier (a rank that failed would otherwise leave the rest waiting there until the RCCL timeout)."""
+    outcome, caught = [], None
     try:
         for k in _my_folds(repo, shard_folds):
-            result = one_fold(Fold(repo, k))
-    except BaseException as exception:                      # noqa: B902 -- re-raised on every rank below
-        error = exception
+            outcome = job(Fold(repo, k))
+    except Exception as exception:
+        caught = exception
     if shard_folds:
-        dist.agree_on_failure(error)
-    elif error is not None:
-        raise error
-    return result
+        dist.agree_on_failure(caught)
+    elif caught is not None:
+        raise caught
+    return outcome
+
+
+def _is_collector(shard_folds: bool) -> bool:
+    """After a sharded pass: wait for every rank, then only rank 0 concatenates."""
+    if dist.is_distributed() and shard_folds:
+        dist.barrier()
+        return dist.env_rank_world()[0] == 0
+    return True
 
 
 def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | None, is_isotropic: bool | None,
         ignore_exceptions: bool = False, kernel_parameters: Kernel.Data | None = None, likelihood_variance: np.ndarray | None = None,
-        is_calibrated: bool = True, is_tested: bool = True, shard_folds: bool = True, **kwargs: Any) -> List[str]:
-    """GPR on a Fold, or across the Folds of a Repository (sharded over ranks when distributed, unless ``shard_folds`` is False:
-    a rank that owns a whole repository -- one output of ``Y_splits_sharded`` -- runs all of its folds itself).
-
-    ``is_read`` None = warm start from the nearest calibrated ancestor (the independent '.v' model of the same isotropy before
-    the '.i' model, user/run.py:75-84); ``is_isotropic`` None = run isotropic then anisotropic; ``is_covariant`` None = run the
-    independent GPs, then the covariant GP warm-started from them (user/run.py:69-73). Returns the model names.
+        is_calibrated: bool = True, is_tested: bool = True, shard_folds: bool = True, **kwargs: Any) -> list[str]:
+    """Fit (and test) GPs on a Fold, or on every fold of a Repository followed by the cross-fold csv collection. ``None`` for
+    ``is_read`` / ``is_covariant`` / ``is_isotropic`` means warm start / both / both (module docstring). ``shard_folds=False`` keeps all
+    folds on the calling rank (a rank that owns a whole ``Y.l`` repository, ``Y_splits_sharded``). Returns the model names, in plan order.
     """
-    if not isinstance(repo, Fold):
-        names: List[str] = _over_folds(repo, shard_folds, lambda fold: gpr(name, fold, is_read, is_covariant, is_isotropic, ignore_exceptions,
-                                                                          kernel_parameters, likelihood_variance, is_calibrated, is_tested, **kwargs))
-        if dist.is_distributed() and shard_folds:
-            dist.barrier()
-            if not names:                                   # a rank that owned no fold still needs the names for the return value
-                names = _names(name, is_covariant, is_isotropic)
-            if dist.env_rank_world()[0] != 0:
-                return names
-        if is_tested:
-            results.Collect({'test': {'header': [0, 1]}, 'test_summary': {'header': [0, 1], 'index_col': 0}}, {n: {} for n in names},
-                            ignore_exceptions).from_folds(repo, True)
-        results.Collect({'variance': {}, 'log_marginal': {}}, {f'{n}/likelihood': {} for n in names}, ignore_exceptions).from_folds(repo, True)
-        results.Collect({'variance': {}, 'lengthscales': {}}, {f'{n}/kernel': {} for n in names}, ignore_exceptions).from_folds(repo, True)
+    plan = _plan(is_read, is_covariant, is_isotropic)
+    names = [variant.model_name(name) for variant in plan]
+
+    def on_fold(fold: Fold) -> list[str]:
+        for variant, model_name in zip(plan, names):
+            resume = _resolve_warm_start(fold, name, variant) if variant.start is None else variant.start
+            with contexts.Timer(f'fold.{fold.meta["k"]} {model_name} GPR'):
+                gp = None
+                try:
+                    fresh = () if resume else (kernel_parameters, likelihood_variance)
+                    gp = MOGP(model_name, fold, resume, variant.covariant, variant.isotropic, *fresh)
+                    if is_calibrated:
+                        gp.calibrate(**kwargs)
+                    if is_tested:
+                        gp.test()
+                except Exception:
+                    if not ignore_exceptions:
+                        raise
+                finally:
+                    if gp is not None:
+                        gp.close()
         return names
-    if is_covariant is None:
-        names = gpr(name, repo, is_read, False, is_isotropic, ignore_exceptions, kernel_parameters, likelihood_variance, is_calibrated, is_tested,
-                    **kwargs)
-        return names + gpr(name, repo, None, True, False if is_isotropic is None else is_isotropic, ignore_exceptions, kernel_parameters,
-                           likelihood_variance, is_calibrated, is_tested, **kwargs)
-    full_name = name + ('.c' if is_covariant else '.v')
-    if is_isotropic is None:
-        names = gpr(name, repo, is_read, is_covariant, True, ignore_exceptions, kernel_parameters, likelihood_variance, is_calibrated, is_tested, **kwargs)
-        return names + gpr(name, repo, None, is_covariant, False, ignore_exceptions, kernel_parameters, likelihood_variance, is_calibrated,
-                           is_tested, **kwargs)
-    full_name = full_name + ('.i' if is_isotropic else '.a')
-    if is_read is None:
-        if not (repo.folder / full_name).exists():
-            nearest_name = name + '.v' + full_name[-2:]
-            if not (is_covariant and (repo.folder / nearest_name).exists()):
-                nearest_name = full_name[:-2] + '.i'
-            if not (repo.folder / nearest_name).exists():
-                return gpr(name, repo, False, is_covariant, is_isotropic, ignore_exceptions, kernel_parameters, likelihood_variance,
-                           is_calibrated, is_tested, **kwargs)
-            GPR.Data.copy(src_folder=repo.folder / nearest_name, dst_folder=repo.folder / full_name)
-        return gpr(name, repo, True, is_covariant, is_isotropic, ignore_exceptions, kernel_parameters, likelihood_variance, is_calibrated,
-                   is_tested, **kwargs)
-    with contexts.Timer(f'fold.{repo.meta["k"]} {full_name} GPR'):
-        gp = None
-        try:
-            if is_read:
-                gp = MOGP(full_name, repo, is_read, is_covariant, is_isotropic)
-            else:
-                gp = MOGP(full_name, repo, is_read, is_covariant, is_isotropic, kernel_parameters, likelihood_variance)
-            if is_calibrated:
-                gp.calibrate(**kwargs)
-            if is_tested:
-                gp.test()
-        except BaseException as exception:
-            if not ignore_exceptions:
-                raise exception
-        finally:
-            if gp is not None:
-                gp.close()
-    return [full_name]
+
+    if isinstance(repo, Fold):
+        return on_fold(repo)
+    _each_fold(repo, shard_folds, on_fold)
+    if _is_collector(shard_folds):
+        per_model = {
+            '': ({'test': {'header': [0, 1]}, 'test_summary': {'header': [0, 1], 'index_col': 0}} if is_tested else {}),
+            '/likelihood': {'variance': {}, 'log_marginal': {}},
+            '/kernel': {'variance': {}, 'lengthscales': {}},
+        }
+        for sub_folder, csvs in per_model.items():
+            if csvs:
+                results.Collect(csvs, {f'{n}{sub_folder}': {} for n in names}, ignore_exceptions).from_folds(repo, True)
+    return names
 
 
-def Y_splits_sharded(repo: Repository) -> List[Repository]:
-    """Independent outputs, one repository each (the reference's ``Repository.Y_split``, data/storage.py:226-243), dealt
-    round-robin to the ranks of the job: rank 0 writes the ``Y.l`` folders, every rank returns ITS share after the barrier.
-    Each ``Y.l`` is an ordinary single-output Repository: fold it and pass it to ``gpr`` with ``shard_folds=False`` (BASELINE
-    configs[3]: one output per GPU), then call ``gsa_outputs`` on the parent for the full (L, L) Sobol matrices, cross-output entries
-    included."""
+def Y_splits_sharded(repo: Repository) -> list[Repository]:
+    """The single-output ``Y.l`` repositories of ``repo`` (``Repository.Y_split``, written by rank 0) dealt round-robin to the ranks;
+    returns this rank's share. Each is an ordinary repository: fold it, ``gpr(..., shard_folds=False)`` it (BASELINE configs[3]: one
+    output per GPU), then ``gsa_outputs`` on the parent gives the full (L, L) Sobol matrices, cross-output entries included."""
     rank, world, _ = dist.env_rank_world()
     if rank == 0:
         repo.Y_split()
@@ -127,104 +162,114 @@ def Y_splits_sharded(repo: Repository) -> List[Repository]:
     return [Repository(splits[i][1]) for i in mine]
 
 
-def _names(name: str, is_covariant: Optional[bool], is_isotropic: Optional[bool]) -> List[str]:
-    if is_covariant is None:
-        return _names(name, False, is_isotropic) + _names(name, True, False if is_isotropic is None else is_isotropic)
-    base = name + ('.c' if is_covariant else '.v')
-    return [base + '.i', base + '.a'] if is_isotropic is None else [base + ('.i' if is_isotropic else '.a')]
+def _sobol_csvs(is_error_calculated: bool) -> dict:
+    return {stem: {} for stem in (('S', 'V', 'T', 'W') if is_error_calculated else ('S', 'V'))}
 
 
 def gsa(name: str, repo: Repository, is_covariant: Optional[bool], is_isotropic: Optional[bool],
         kinds: GSA.Kind | Sequence[GSA.Kind] = GSA.ALL_KINDS, m: int = -1, ignore_exceptions: bool = False,
-        is_error_calculated: bool = False, shard_folds: bool = True, **kwargs: Any) -> List[Path]:
-    """GSA on a Fold, or across the Folds of a Repository (sharded over ranks when distributed and ``shard_folds``). Always resumes
-    from the GP stored by ``gpr`` (is_read=True, user/run.py:151). Returns the calculation folders relative to the fold."""
-    kinds = (kinds,) if isinstance(kinds, GSA.Kind) else kinds
-    if not isinstance(repo, Fold):
-        names: List[Path] = _over_folds(repo, shard_folds, lambda fold: gsa(name, fold, is_covariant, is_isotropic, kinds, m, ignore_exceptions,
-                                                                           is_error_calculated, **kwargs))
-        if dist.is_distributed() and shard_folds:
-            dist.barrier()
-            if dist.env_rank_world()[0] != 0:
-                return names
-            if not names:
-                return names
-        results.Collect({'S': {}, 'V': {}} | ({'T': {}, 'W': {}} if is_error_calculated else {}), {n: {} for n in names},
-                        ignore_exceptions).from_folds(repo, True)
-        for n in names:
+        is_error_calculated: bool = False, shard_folds: bool = True, **kwargs: Any) -> list[Path]:
+    """Closed-form Sobol indices of the GPs ``gpr`` stored (always resumed from disk), on a Fold or on every fold of a Repository followed
+    by the cross-fold collection. Returns the calculation folders relative to the fold, in plan x kind order."""
+    kinds = (kinds,) if isinstance(kinds, GSA.Kind) else tuple(kinds)
+    plan = _plan(True, is_covariant, is_isotropic)
+
+    def on_fold(fold: Fold) -> list[Path]:
+        done: list[Path] = []
+        for variant in plan:
+            model_name = variant.model_name(name)
+            with contexts.Timer(f'fold.{fold.meta["k"]} {model_name} GSA'):
+                gp = None
+                try:
+                    gp = MOGP(model_name, fold, is_read=True, is_covariant=variant.covariant, is_isotropic=variant.isotropic)
+                    for kind in kinds:
+                        where = Sobol(gp, kind, m, is_error_calculated, **kwargs).calibrate().get('folder')
+                        done.append(Path(where).relative_to(fold.folder))
+                except Exception:
+                    if not ignore_exceptions:
+                        raise
+                finally:
+                    if gp is not None:
+                        gp.close()
+        return done
+
+    if isinstance(repo, Fold):
+        return on_fold(repo)
+    done = _each_fold(repo, shard_folds, on_fold)
+    if _is_collector(shard_folds) and done:
+        results.Collect(_sobol_csvs(is_error_calculated), {n: {} for n in done}, ignore_exceptions).from_folds(repo, True)
+        for n in done:
             shutil.copyfile(repo.fold_folder(repo.folds.start) / n / 'meta.json', repo.folder / n / 'meta.json')
-        return names
-    if is_covariant is None:                                 # independent then covariant (user/run.py:137-140)
-        names = gsa(name, repo, False, is_isotropic, kinds, m, ignore_exceptions, is_error_calculated, **kwargs)
-        return names + gsa(name, repo, True, False if is_isotropic is None else is_isotropic, kinds, m, ignore_exceptions,
-                           is_error_calculated, **kwargs)
-    full_name = name + ('.c' if is_covariant else '.v')
-    if is_isotropic is None:
-        names = gsa(name, repo, is_covariant, True, kinds, m, ignore_exceptions, is_error_calculated, **kwargs)
-        return names + gsa(name, repo, is_covariant, False, kinds, m, ignore_exceptions, is_error_calculated, **kwargs)
-    full_name = full_name + ('.i' if is_isotropic else '.a')
-    names = []
-    with contexts.Timer(f'fold.{repo.meta["k"]} {full_name} GSA'):
-        gp = None
-        try:
-            gp = MOGP(full_name, repo, is_read=True, is_covariant=is_covariant, is_isotropic=is_isotropic)
-            for kind in kinds:
-                folder = Sobol(gp, kind, m, is_error_calculated, **kwargs).calibrate().get('folder')
-                names += [Path(folder).relative_to(repo.folder)]
-        except BaseException as exception:
-            if not ignore_exceptions:
-                raise exception
-        finally:
-            if gp is not None:
-                gp.close()
-    return names
+    return done
+
+
+def _agreed_fold_table(first_split: Path) -> tuple[list[int], dict[int, tuple[int, int]]]:
+    """Folds of the ``Y.l`` repositories and the (N, M) of each, as rank 0 sees them after everybody's fits are on disk, handed to every
+    rank -- so that all ranks walk the same fold list even if their view of the shared folder lags."""
+    rank, world, _ = dist.env_rank_world()
+    table = None
+    if rank == 0:
+        first = Repository(first_split, meta_only=True)
+        table = [(int(k), int(Fold(first, k).N), int(first.M)) for k in first.folds]
+    if dist.is_distributed():
+        table = dist.broadcast_object(table)
+    return [k for k, _, _ in table], {k: (n, mm) for k, n, mm in table}
 
 
 def gsa_outputs(name: str, repo: Repository, is_isotropic: bool, kinds: GSA.Kind | Sequence[GSA.Kind] = GSA.ALL_KINDS, m: int = -1,
-                is_error_calculated: bool = False, **kwargs: Any) -> List[Path]:
+                is_error_calculated: bool = False, **kwargs: Any) -> list[Path]:
     """GSA of L independent outputs whose GPs live in the ``Y.l`` split repositories of ``repo``, one output (or a few) per rank
     (``Y_splits_sharded`` + ``gpr(..., shard_folds=False)`` before this). Produces what the single-process
     ``gsa(name, repo, is_covariant=False, ...)`` on the L-output repository produces -- ``fold.k/<name>.v.<i|a>/gsa/<kind>/S.csv,
     V.csv[, T.csv, W.csv]`` with all (l.0, l.1) rows, cross-output entries included (gsa/calibrators.py:79, gsa/models.py:66-75) --
     written by rank 0 into ``repo``'s fold folders. Per fold the ranks exchange (K_inv_Y, lengthscales, variance) of their outputs
-    in one all-gather and the finished rows in another (``gpr.sharded.OutputShard``); every rank walks every fold."""
+    in one all-gather and the finished rows in another (``gpr.sharded.OutputShard``); every rank walks every fold.
+
+    Ordering in a job: a barrier first (every rank's fits and folds are on disk before anyone reads another rank's folder); per fold
+    the fallible LOCAL work -- reading this rank's stored GPs -- comes first and the ranks agree on its success BEFORE the first
+    collective of that fold, so a missing model stops all ranks together instead of leaving some inside an all-gather. A failure after
+    that point (inside the collectives) is not recoverable in step and propagates as it is."""
     from romcomma_amd.gpr.sharded import OutputShard
-    kinds = (kinds,) if isinstance(kinds, GSA.Kind) else kinds
+    kinds = (kinds,) if isinstance(kinds, GSA.Kind) else tuple(kinds)
     rank, world, _ = dist.env_rank_world()
+    if dist.is_distributed():
+        dist.barrier()
     splits = sorted(repo.Y_splits)
     L = len(splits)
     if L == 0:
         raise FileNotFoundError(f'{repo.folder} has no Y.l splits: call Y_splits_sharded(repo) and fit them first')
     owned = dist.shard_units(L, rank, world) if world > 1 else list(range(L))
-    full_name = name + '.v' + ('.i' if is_isotropic else '.a')
-    first = Repository(splits[0][1])
-    names: List[Path] = []
-    error = None
-    try:
-        for k in first.folds:
-            with contexts.Timer(f'fold.{k} {full_name} GSA over {L} outputs, {len(owned)} here'):
-                shard = None
-                gps = {}
-                try:
-                    for i in owned:
-                        gps[splits[i][0]] = MOGP(full_name, Fold(Repository(splits[i][1]), k), is_read=True, is_covariant=False, is_isotropic=is_isotropic)
-                    fold_meta = Fold(first, k).meta['data']
-                    shard = OutputShard(gps, L, repo.fold_folder(k) / full_name, N=fold_meta['N'], M=fold_meta['M'])
-                    names = []
-                    for kind in kinds:
-                        folder = Sobol(shard, kind, m, is_error_calculated, **kwargs).calibrate().get('folder')
-                        names += [Path(folder).relative_to(shard.folder.parent)]
-                finally:
-                    if shard is not None:
-                        shard.close()
-                    else:
-                        for gp in gps.values():
-                            gp.close()
-    except BaseException as exception:                      # noqa: B902
-        error = exception
-    dist.agree_on_failure(error)
+    model_name = _Variant(False, is_isotropic).model_name(name)
+    folds, shape_of = _agreed_fold_table(splits[0][1])
+    done: list[Path] = []
+    for k in folds:
+        with contexts.Timer(f'fold.{k} {model_name} GSA over {L} outputs, {len(owned)} here'):
+            gps, caught = {}, None
+            try:
+                for i in owned:
+                    gps[splits[i][0]] = MOGP(model_name, Fold(Repository(splits[i][1]), k), is_read=True, is_covariant=False,
+                                             is_isotropic=is_isotropic)
+            except Exception as exception:
+                caught = exception
+            try:
+                dist.agree_on_failure(caught)
+            except Exception:
+                for gp in gps.values():
+                    gp.close()
+                raise
+            N, M = shape_of[k]
+            shard = None
+            try:
+                shard = OutputShard(gps, L, repo.fold_folder(k) / model_name, N=N, M=M)
+                done = []
+                for kind in kinds:
+                    where = Sobol(shard, kind, m, is_error_calculated, **kwargs).calibrate().get('folder')
+                    done.append(Path(where).relative_to(shard.folder.parent))
+            finally:
+                for closable in ([shard] if shard is not None else gps.values()):
+                    closable.close()
     if dist.is_distributed():
         dist.barrier()
-    if rank == 0 and names and repo.K > 0 and all((repo.fold_folder(k) / 'meta.json').exists() for k in repo.folds):
-        results.Collect({'S': {}, 'V': {}} | ({'T': {}, 'W': {}} if is_error_calculated else {}), {n: {} for n in names}).from_folds(repo, True)
-    return names
+    if rank == 0 and done and repo.K > 0 and all((repo.fold_folder(k) / 'meta.json').exists() for k in repo.folds):
+        results.Collect(_sobol_csvs(is_error_calculated), {n: {} for n in done}).from_folds(repo, True)
+    return done

@@ -200,3 +200,49 @@ def test_bench_fold_schedule():
         assert sorted(bench.fold_schedule(r, 1, 3, 8)[1 + s] for r in range(8)) == list(range(8))
     totals = {tuple(sorted(bench.fold_schedule(r, 0, 8, 8))) for r in range(8)}
     assert totals == {tuple(range(8))}                                   # over 8 steps every rank has fitted every fold once
+
+
+def test_run_plan_and_warm_start_table(tmp_path):
+    """user/run.py expands the None options once into an ordered plan (reference behaviour: user/run.py:69-93, 137-147): independent
+    before covariant, isotropic before anisotropic, every later model warm-started; names <name>.<c|v>.<i|a>."""
+    from romcomma_amd.user import run
+    names = lambda *options: [(v.model_name('gpr'), v.start) for v in run._plan(*options)]
+    assert names(False, False, False) == [('gpr.v.a', False)]
+    assert names(True, True, True) == [('gpr.c.i', True)]
+    assert names(False, False, None) == [('gpr.v.i', False), ('gpr.v.a', None)]
+    assert names(None, None, False) == [('gpr.v.a', None), ('gpr.c.a', None)]
+    assert names(False, None, None) == [('gpr.v.i', False), ('gpr.v.a', None), ('gpr.c.a', None)]       # covariant: anisotropic only
+    assert names(True, None, True) == [('gpr.v.i', True), ('gpr.c.i', None)]
+    # warm start on a fold folder: own folder > independent model of the same isotropy (covariant only) > isotropic model > fresh
+    fold = type('F', (), {'folder': tmp_path})()
+    store = lambda model: (tmp_path / model / 'kernel').mkdir(parents=True) or (tmp_path / model / 'kernel' / 'variance.csv').write_text('x')
+    cov_a, ind_a, ind_i = run._Variant(True, False, None), run._Variant(False, False, None), run._Variant(False, True, None)
+    assert cov_a.relatives('gpr') == ['gpr.v.a', 'gpr.c.i'] and ind_a.relatives('gpr') == ['gpr.v.i']
+    assert run._resolve_warm_start(fold, 'gpr', ind_i) is False                       # nothing stored: its only relative is itself
+    assert run._resolve_warm_start(fold, 'gpr', cov_a) is False and not (tmp_path / 'gpr.c.a').exists()
+    store('gpr.v.i')
+    assert run._resolve_warm_start(fold, 'gpr', ind_i) is True
+    assert run._resolve_warm_start(fold, 'gpr', ind_a) is True and (tmp_path / 'gpr.v.a' / 'kernel' / 'variance.csv').exists()   # copied from .v.i
+    (tmp_path / 'gpr.v.a' / 'kernel' / 'variance.csv').write_text('anisotropic')
+    assert run._resolve_warm_start(fold, 'gpr', cov_a) is True
+    assert (tmp_path / 'gpr.c.a' / 'kernel' / 'variance.csv').read_text() == 'anisotropic'                # .v.a preferred to .c.i
+    (tmp_path / 'gpr.c.a' / 'kernel' / 'variance.csv').write_text('own')
+    assert run._resolve_warm_start(fold, 'gpr', cov_a) is True and (tmp_path / 'gpr.c.a' / 'kernel' / 'variance.csv').read_text() == 'own'
+
+
+def test_fold_deal_is_balanced_and_seeded():
+    from romcomma_amd.data.storage import _deal
+    label = _deal(61, 4, np.random.default_rng(3))
+    assert sorted(np.bincount(label)) == [15, 15, 15, 16] and np.bincount(label)[0] == 16          # fold k < N mod K is the larger kind
+    assert all(sorted(label[i:i + 4]) == [0, 1, 2, 3] for i in range(0, 60, 4))                    # every hand of K deals each fold once
+    assert np.array_equal(label, _deal(61, 4, np.random.default_rng(3))) and not np.array_equal(label, _deal(61, 4, np.random.default_rng(4)))
+    assert list(_deal(5, 1, np.random.default_rng(0))) == [0] * 5
+
+
+def test_meta_json_is_replaced_atomically(tmp_path):
+    repo = make_repo(tmp_path / 'repo')
+    repo.meta['K'] = 3
+    repo.write_meta()
+    assert json.loads((tmp_path / 'repo' / 'meta.json').read_text())['K'] == 3
+    assert [p.name for p in (tmp_path / 'repo').iterdir() if p.name.endswith('.tmp')] == []
+    assert (tmp_path / 'repo' / 'meta.json').read_text().startswith('{\n        "')                 # indent 8
