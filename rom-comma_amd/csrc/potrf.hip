@@ -338,12 +338,100 @@ __device__ __forceinline__ double xval(const double* S, const double* Xd, int i,
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// chol128_regs: the 16-blocked Cholesky of the 128x128 block with the TRAILING MATRIX IN REGISTERS (k_diag2<MODE, true>).
+// In k_diag2's first form every trailing tile update is LDS -> accumulator -> 4 MFMAs -> LDS (12 LDS reads + 4 writes per tile and
+// step) and the pivot wave starts each step with one of them; here a tile of the trailing matrix stays in the accumulator registers of
+// the wave that owns it from the first load to the panel step that makes it final, and LDS (the array S) only ever receives FINAL
+// tiles of L -- which is also where the panel and trailing products read their operands from.
+//   Tile layout, the same for every 16x16 tile held in registers: lane (fr = lane & 15, fq = lane >> 4), register q holds
+//   T[fr][4q + fq]. For a tile of the symmetric trailing matrix, S_{rb,cb}, that IS the MFMA C/D layout of U = S_{rb,cb}^T
+//   (row 4q + fq, column fr), and the same four registers are the B operand (k = 4s + fq, s = q) of  L_{rb,c}^T = X_cc * U  -- the panel
+//   solve needs no transposition through LDS -- whose result comes out in the same layout again.
+//   Trailing update in that layout:  U_{cb,rb} -= L_{cb,c} * L_{rb,c}^T  (A = L_{cb,c}, B = L_{rb,c}^T, both read from S; neg A by the MFMA).
+//   Ownership (static; rc_tile_owner): wave k owns the diagonal tile (k,k) -- it factors pivot block k -- and the tile (k,k-1) to its
+//   left; its three other tiles lie in block columns < k. So at step c the NEXT pivot wave (c + 1) has exactly one trailing update to do,
+//   its own diagonal tile, and goes straight on to the pivot block while the other seven waves update everything else: nothing
+//   but that one tile update (4 MFMAs) and the panel tile (c+1, c) (4 MFMAs) sits between two pivot blocks.
+//   Two workgroup barriers per step: X_cc published -> panel column c; panel column c in S -> trailing updates.
+// ---------------------------------------------------------------------------------------------------------------------
+#define RC_REG_SLOTS 5
+__device__ __constant__ signed char rc_tile_owner[8][RC_REG_SLOTS][2] = {      // [wave][slot] = {rb, cb}; rb < 0: no tile
+    {{0, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}},
+    {{1, 1}, {1, 0}, {2, 0}, {3, 0}, {4, 0}},
+    {{2, 2}, {2, 1}, {5, 0}, {6, 0}, {3, 1}},
+    {{3, 3}, {3, 2}, {7, 0}, {4, 1}, {5, 1}},
+    {{4, 4}, {4, 3}, {6, 1}, {7, 1}, {4, 2}},
+    {{5, 5}, {5, 4}, {5, 2}, {6, 2}, {7, 2}},
+    {{6, 6}, {6, 5}, {5, 3}, {6, 3}, {7, 3}},
+    {{7, 7}, {7, 6}, {6, 4}, {7, 4}, {7, 5}}};
+
+__device__ __forceinline__ void chol128_regs(double* S, double* Xd, double* rsd, double* pcol, double* lt, int* info, int64_t j0) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  int rbs[RC_REG_SLOTS], cbs[RC_REG_SLOTS];
+  v4d acc[RC_REG_SLOTS];
+#pragma unroll
+  for (int k = 0; k < RC_REG_SLOTS; ++k) {
+    rbs[k] = __builtin_amdgcn_readfirstlane((int)rc_tile_owner[wave][k][0]);
+    cbs[k] = __builtin_amdgcn_readfirstlane((int)rc_tile_owner[wave][k][1]);
+    acc[k] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (rbs[k] >= 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[k][q] = S[(16 * rbs[k] + fr) * LS + 16 * cbs[k] + 4 * q + fq];
+    }
+  }
+  // (no barrier: S is not written before every wave has passed the first one below -- wave 0 rewrites only its own tile (0,0))
+#pragma unroll 1
+  for (int c = 0; c < 8; ++c) {
+    if (wave == c) {                                  // pivot block c: the owner puts its diagonal tile where pivot_block_16 works in place
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[(16 * c + fr) * LS + 16 * c + 4 * q + fq] = acc[0][q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      pivot_block_16(S, Xd, rsd, pcol, lt, info, j0, c, lane);
+    }
+    __syncthreads();                                  // X_cc (Xd[c]) and L_cc are visible
+    RC_T(2 + 2 * c);
+    if (c == 7) break;
+    double xa[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xa[s] = Xd[(c * 16 + fr) * XS + 4 * s + fq];            // A operand: X_cc[fr][4s + fq]
+#pragma unroll
+    for (int k = 1; k < RC_REG_SLOTS; ++k) {          // panel: this wave's tiles of block column c become final
+      if (rbs[k] >= 0 && cbs[k] == c) {
+        v4d d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) d = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s], acc[k][s], d, 0, 0, 0);
+        acc[k] = d;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[(16 * rbs[k] + fr) * LS + 16 * c + 4 * q + fq] = d[q];
+      }
+    }
+    __syncthreads();                                  // block column c of L is in S
+    RC_T(3 + 2 * c);
+#pragma unroll
+    for (int k = 0; k < RC_REG_SLOTS; ++k) {          // trailing: slot 0 (the diagonal tile) first -- the next pivot wave has only that one
+      if (rbs[k] >= 0 && cbs[k] > c) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          av[s] = S[(16 * cbs[k] + fr) * LS + 16 * c + 4 * s + fq];                     // L_{cb,c}[fr][4s + fq], negated by the MFMA
+          bv[s] = S[(16 * rbs[k] + fr) * LS + 16 * c + 4 * s + fq];                     // L_{rb,c}[fr][4s + fq]
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc[k], 0, 0, 1);
+      }
+    }
+  }
+}
+
 // MODE 0: the whole job (factor, invert, w_j). MODE 1: factor only -- L_jj, log L_ii and the eight 16x16 diagonal-block inverses
 // (written into the diagonal 16-blocks of invL) -- which is all the NEXT chain step needs (k_prep1s solves the tile below by
 // substitution): the 128x128 inverse and w_j are 15 us of this kernel and come off the critical path. MODE 2: the rest, as a kernel
 // of its own on the column-work stream: reads L_jj and the diagonal-block inverses back, completes the right-hand side rows of
 // this block (rhs_j -= L(j, j-1) w_{j-1}: the block row the chain no longer updates), inverts, emits invL and w_j.
-template <int MODE>
+template <int MODE, bool REG = false>
 __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
                                            double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
   // S: [128][LS], then Xd[8][16][XS], rsd[128], rv[128]   (dynamic shared memory of the calling kernel)
@@ -403,7 +491,10 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
   __syncthreads();
   RC_T(1);
 
-  if (MODE != 2) {
+  if (MODE != 2 && REG) {
+    chol128_regs(S, Xd, rsd, pcol, lt, info, j0);
+  }
+  if (MODE != 2 && !REG) {
   // ------------------------------------------------------------------ blocked Cholesky
   // Iteration c: (a) trailing update with block column c-1 of the lower tiles (rb, cb), c <= cb <= rb -- tile (c, c) goes to
   // wave 0, which then factors that pivot block while the other waves finish the remaining tiles; (b) panel below the pivot block.
@@ -455,7 +546,8 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
     __syncthreads();
     RC_T(3 + 2 * c);
   }
-
+  }  // MODE != 2 && !REG
+  if (MODE != 2) {
   // L back to global (lower + diagonal, zeros above), log-diagonal
   for (int e = t; e < 128 * 64; e += 512) {
     const int i = e >> 6, j = (e & 63) * 2;
@@ -567,11 +659,11 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
   RC_SPAN(1);
 }
 
-template <int MODE>
+template <int MODE, bool REG = false>
 __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
                                                double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
   extern __shared__ double S[];
-  diag2_body<MODE>(S, A, ld, invL, rhs, logdiag, info, j0);
+  diag2_body<MODE, REG>(S, A, ld, invL, rhs, logdiag, info, j0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -640,14 +732,19 @@ int rc_launch_diag(rcgp_handle_s* h, int64_t j, int mode) {
       RC_HIP(hipFuncSetAttribute((const void*)k_diag2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       RC_HIP(hipFuncSetAttribute((const void*)k_diag2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       RC_HIP(hipFuncSetAttribute((const void*)k_diag2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      RC_HIP(hipFuncSetAttribute((const void*)k_diag2<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      RC_HIP(hipFuncSetAttribute((const void*)k_diag2<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       h->diag_attr_set = true;
     }
+    const bool reg = h->diag_variant == 3;
     if (mode == 1) {
-      RC_LAUNCH(k_diag2<1>, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
+      if (reg) RC_LAUNCH((k_diag2<1, true>), dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
+      else RC_LAUNCH(k_diag2<1>, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
     } else if (mode == 2) {
       RC_LAUNCH(k_diag2<2>, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
     } else {
-      RC_LAUNCH(k_diag2<0>, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
+      if (reg) RC_LAUNCH((k_diag2<0, true>), dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
+      else RC_LAUNCH(k_diag2<0>, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
     }
   }
   RC_HIP(hipGetLastError());
