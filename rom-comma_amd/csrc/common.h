@@ -45,7 +45,7 @@ struct rcgp_handle_s {
   hipStream_t stream6 = nullptr;     // the far part of that column work (block columns the next chain step does not read)
   int prep_split = 2;                // the chain's critical step: 3 = factor-only diagonal kernel + k_prep1s (substitution) + k_prep2, the 128x128 inverse
                                      // off the critical path; 2 / 1 = k_prep1 (explicit inverse; 8 / 4 waves) + k_prep2; 0 = k_prep_next on one CU (RCGP_PSPLIT)
-  bool prep_attr_set = false, prep_s_attr_set = false;
+  bool prep_attr_set = false, prep_s_attr_set = false, subst_attr_set = false;
   int grad_order = 0;                // k_grad tile order: 0 = heavy-first rows; 1 = 8 x 8 super-blocks per XCD with a common k start (measured: HBM reads -7 %,
                                      // time +13 % -- prefetching workgroups drift apart) (RCGP_GRAD_ORDER)
   bool prep_small = false;           // the tile solve as 32 small workgroups (k_prep1q + k_prep2r) instead of 8 whole-CU ones (RCGP_PREP_SMALL)
@@ -87,6 +87,7 @@ struct rcgp_handle_s {
   int chain_depth = 2;               // column panels updated by their own kernels ahead of the bulk trailing update (RCGP_DEPTH >= 1)
   int chain_ext = 4;                 // 128-blocks past its own panel that a chain step keeps up to date (RCGP_EXT >= 1)
   bool diag_attr_set = false;
+  bool invdiag_full = true;          // invdiag holds the full 128x128 inverses (false after a substitution-based factorisation: only their 16x16 diagonal blocks)
   int diag_variant = 2;              // 2 = MFMA 16-blocked kernel (k_diag2), 1 = register column sweep (k_diag)
   int64_t N = 0, Np = 0;       // training rows per output; rows of the whole system, L * Nb
   int64_t Nb = 0;              // N padded to a multiple of RC_TILE: rows of one output block (Nb == Np when L == 1)
@@ -226,6 +227,9 @@ int rc_launch_prep_split(rcgp_handle_s* h, double* T, double* D, int64_t ld, con
 // inverses, which the factor-only diagonal kernel leaves in invL); the right-hand side is not touched
 int rc_launch_prep_subst(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL);
 // k_prep1g (the inverse read straight from global memory into MFMA fragments: 17 KB of LDS, fits any free slot) + k_prep2
+// substitution-based panel solve (k_trsm_subst) for m rows, and the chain's tile with the next diagonal block's update fused
+int rc_launch_trsm_subst(rcgp_handle_s* h, double* P, int64_t ldp, const double* Ljj, const double* invL, int64_t m, double* rhs, const double* wj);
+int rc_launch_chain_tile(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL, double* rhs, const double* wj);
 int rc_launch_prep_g(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
 // k_prep1q (32 small workgroups, 49.5 KB of LDS) + k_prep2r (diagonal-block update, rhs rows, optional `ready` signal of the resident diagonal workgroup)
 int rc_launch_prep_q(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj, int* ctr,
@@ -247,7 +251,8 @@ int rc_launch_vtv(rcgp_handle_s* h, int64_t rows_padded, const double* V, double
 // ---- potrf.hip
 int rc_potrf(rcgp_handle_s* h);                              // blocked Cholesky of A in place, w = L^-1 y, logdiag
 int rc_launch_diag_loop(rcgp_handle_s* h, unsigned long long base);   // the resident diagonal workgroup (k_diag_loop) on h->launch
-int rc_launch_diag(rcgp_handle_s* h, int64_t j, int mode = 0);   // diagonal block at row/col offset j: 0 = factor + invert + w_j, 1 = factor only, 2 = invert + w_j
+int rc_launch_diag(rcgp_handle_s* h, int64_t j, int mode = 0);
+int rc_launch_inv128_batched(rcgp_handle_s* h);                  // every 128x128 inverse of the factor's diagonal blocks, one launch on h->launch   // diagonal block at row/col offset j: 0 = factor + invert + w_j, 1 = factor only, 2 = invert + w_j
 
 // ---- solve.hip
 int rc_trtri_begin(rcgp_handle_s* h);                        // allocate Linv/S, reset the incremental schedule

@@ -734,6 +734,139 @@ __global__ void __launch_bounds__(256) k_prep1s(double* T, int64_t ld, const dou
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_trsm_subst: a 128-row tile of the panel solve  X L_jj^T = T  by blocked forward substitution against L_jj ITSELF -- no 128x128
+// inverse anywhere on the factorisation's critical path (the diagonal kernel then only factors: 11 us less per chain step). What
+// it needs of L_jj are its 28 strictly-lower 16x16 blocks and the inverses of its 8 diagonal blocks (which the factor-only diagonal
+// kernel leaves in the diagonal blocks of invL); they are packed block by block into 77 KB of LDS (PB doubles per block, odd row
+// stride), so two workgroups share a CU.
+// One wave per 16-row strip, the whole recurrence in registers, as in k_prep1s: with Y = X^T the C/D layout of a 16x16
+// MFMA result (lane (fr, fq), register r: row fq + 4r, column fr) is the B-operand layout of the next products (k = 4s + fq, s = r):
+//     Y_c = inv(L_cc) (T^T_c - sum_{k<c} L_ck Y_k),  c = 0..7:   4c + 4 MFMAs, 144 per strip, the same count as the product with the
+// explicit triangular inverse; sequential along c, but an fp64 MFMA occupies the pipe for its whole 64-cycle latency anyway.
+// The strip is read from / written to global memory in that layout directly (lane fr = its row, 32 columns fq + 4r + 16c).
+// Fused: rhs rows -= X w_j (forward substitution of the right-hand side, as in the GEMM form of the panel solve).
+// NS = strips (computing waves) per workgroup; all eight waves of the workgroup bring L_jj into LDS. NS = 4 for the column below (64 rows
+// per workgroup, one computing wave per SIMD), NS = 1 for the chain's own tile (eight workgroups on eight CUs: 12 us against 40 for one
+// workgroup that solves all eight strips and then updates the next diagonal block from them -- measured, that form is gone).
+// ---------------------------------------------------------------------------------------------------------------------
+#define PBS 17                     // row stride of a packed 16x16 block
+#define PB (16 * PBS)              // doubles per packed block
+__device__ __forceinline__ int rc_packed_block(int rb, int cb) { return rb * (rb + 1) / 2 + cb; }
+
+template <int NS>
+__global__ void __launch_bounds__(512, 4) k_trsm_subst(double* __restrict__ P, int64_t ldp, const double* __restrict__ Ljj, int64_t ldl,
+                                                        const double* __restrict__ invL, double* __restrict__ rhs, const double* __restrict__ wj) {
+  extern __shared__ double smts[];                 // Lp[36][PB], wv[128]
+  double* Lp = smts;
+  double* wv = Lp + 36 * PB;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
+  double* T = P + (int64_t)blockIdx.x * (16 * NS) * ldp;
+  double* rhs_t = rhs + (int64_t)blockIdx.x * (16 * NS);
+  // every global load of the kernel in flight before the first wait: L_jj (its 36 lower blocks enumerated directly: 36 x 16 rows x 8
+  // pairs = 9 loads per thread; the diagonal ones from invL) and, for the computing waves, their strip
+  double2 vl[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int e = t + 512 * q, b = e >> 7, i16 = (e >> 3) & 15, j2 = (e & 7) * 2;
+    int rb = 0;
+    while ((rb + 1) * (rb + 2) / 2 <= b) ++rb;
+    const int cb = b - rb * (rb + 1) / 2, i = 16 * rb + i16, j = 16 * cb + j2;
+    vl[q] = (rb == cb) ? *reinterpret_cast<const double2*>(invL + i * 128 + j) : *reinterpret_cast<const double2*>(Ljj + (int64_t)i * ldl + j);
+  }
+  v4d Y[8];
+  double* Tw = T + (int64_t)(16 * (wave < NS ? wave : 0) + fr) * ldp + fq;
+  if (wave < NS) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Y[c][r] = Tw[16 * c + 4 * r];
+  }
+  const double wreg = (t < 128) ? wj[t] : 0.0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int e = t + 512 * q, b = e >> 7, i16 = (e >> 3) & 15, j2 = (e & 7) * 2;
+    double* d = Lp + b * PB + i16 * PBS + j2;      // (block b of the enumeration IS packed block b)
+    d[0] = vl[q].x;                                // (the inverse blocks are lower triangular with stored zeros above their diagonal)
+    d[1] = vl[q].y;
+  }
+  if (t < 128) wv[t] = wreg;
+  __syncthreads();
+  if (wave >= NS) return;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    v4d acc = Y[c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) {
+      const double* blk = Lp + rc_packed_block(c, k) * PB + fr * PBS + fq;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[4 * s2], Y[k][s2], acc, 0, 0, 1);   // - L_ck Y_k
+    }
+    const double* inv = Lp + rc_packed_block(c, c) * PB + fr * PBS + fq;
+    v4d y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) y = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[4 * s2], acc[s2], y, 0, 0, 0);
+    Y[c] = y;
+    // this block column of X is final: out it goes while the recurrence continues
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tw[16 * c + 4 * r] = y[r];
+  }
+  // rhs rows -= X w_j: lane (fr, fq) holds X[fr][16c + fq + 4r]; the four fq lanes of a row are summed in a fixed order
+  double part = 0.0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part = __builtin_fma(Y[c][r], wv[16 * c + 4 * r + fq], part);
+  part += __shfl_xor(part, 16);
+  part += __shfl_xor(part, 32);
+  if (fq == 0) rhs_t[16 * wave + fr] -= part;
+}
+
+#define RC_SUBST_LDS ((size_t)(36 * PB + 128) * sizeof(double))
+
+// Panel solve by substitution for the m rows below (m a multiple of 128): P <- P L_jj^-T, rhs -= P_new w_j. Four strips (64 rows) per
+// workgroup, one computing wave per SIMD: the recurrence of a strip is 144 dependent fp64 MFMAs (64 cycles each: 3.8 us), two strips on
+// one SIMD take twice that.
+int rc_launch_trsm_subst(rcgp_handle_s* h, double* P, int64_t ldp, const double* Ljj, const double* invL, int64_t m, double* rhs, const double* wj) {
+  if (m <= 0) return 0;
+  if (!h->subst_attr_set) {
+    RC_HIP(hipFuncSetAttribute((const void*)k_trsm_subst<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_SUBST_LDS));
+    RC_HIP(hipFuncSetAttribute((const void*)k_trsm_subst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_SUBST_LDS));
+    h->subst_attr_set = true;
+  }
+  RcProfScope ps(h, RC_K_GEMM, (double)m * 128.0 * 128.0, true);
+  RC_LAUNCH(k_trsm_subst<4>, dim3((unsigned)(m / 64)), dim3(512), RC_SUBST_LDS, P, ldp, Ljj, ldp, invL, rhs, wj);
+  RC_HIP(hipGetLastError());
+  return 0;
+}
+
+// The chain's tile: T (128 x 128, right below L_jj) solved -- eight workgroups, one strip each, on eight CUs -- and its rhs rows updated
+// (this dispatch carries a pending h->launch_stop: the column work needs only the solved tile), then D (the next diagonal block)
+// -= T_new T_new^T (k_prep2).
+int rc_launch_chain_tile(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL, double* rhs, const double* wj) {
+  const size_t lds2 = (size_t)(64 * LP) * sizeof(double);
+  if (!h->subst_attr_set) {
+    RC_HIP(hipFuncSetAttribute((const void*)k_trsm_subst<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_SUBST_LDS));
+    RC_HIP(hipFuncSetAttribute((const void*)k_trsm_subst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_SUBST_LDS));
+    h->subst_attr_set = true;
+  }
+  if (!h->prep_s_attr_set) {
+    RC_HIP(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    h->prep_s_attr_set = true;
+  }
+  {
+    RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
+    RC_LAUNCH(k_trsm_subst<1>, dim3(8), dim3(512), RC_SUBST_LDS, T, ld, Ljj, ld, invL, rhs, wj);
+    RC_HIP(hipGetLastError());
+  }
+  {
+    RcProfScope ps(h, RC_K_GEMM, 128.0 * 129.0 * 128.0, true);
+    RC_LAUNCH(k_prep2, dim3(10), dim3(256), lds2, (const double*)T, D, ld);
+    RC_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
 // k_prep1 with the inverse of L_jj read straight from global memory (L2) into the MFMA B fragments instead of through LDS: 17 KB of LDS
 // and 512 threads, so the workgroup fits into ANY free slot of a CU next to a resident GEMM workgroup -- k_prep1's 138 KB need a CU
 // with both slots free at once, for which it waited milliseconds at C2 (kernel trace). One 16-row strip of the tile per workgroup,

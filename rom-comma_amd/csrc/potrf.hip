@@ -250,8 +250,9 @@ __device__ __forceinline__ double rl_d(double v, int lane) {      // broadcast l
 // in ONE batch of 16-byte loads into registers before any of it is used: left to itself the compiler issues read - wait - two FMAs
 // eight times per pivot, i.e. eight exposed LDS latencies instead of one. The same for the inverse, whose column k of L comes
 // from a transposed 16x16 copy (lt) as one contiguous batch per step.
-__device__ __attribute__((noinline)) void pivot_block_16(double* S, double* Xd, double* rsd, double* pcol, double* lt, int* info, int64_t j0, int c,
-                                               int lane) {
+template <bool INL>
+__device__ __forceinline__ void pivot_block_16_body(double* S, double* Xd, double* rsd, double* pcol, double* lt, int* info, int64_t j0, int c,
+                                                    int lane) {
 #ifdef RC_DIAG2_NO_PIVOT
   if (lane < 16) { for (int i = 0; i < 16; ++i) Xd[(c * 16 + i) * XS + lane] = (i == lane) ? 1.0 : 0.0; rsd[16 * c + lane] = 1.0; }
   return;
@@ -330,6 +331,16 @@ __device__ __attribute__((noinline)) void pivot_block_16(double* S, double* Xd, 
       if (lane == j) rsd[16 * c + j] = rsv[j];
     // the strictly-upper part of the diagonal block belongs to nobody: restore zeros (blk was written with zeros above)
   }
+  if (c == 0) RC_T(30);
+}
+
+// Out of line for the first form of k_diag2 (two call sites: inlined twice the kernel spills). NOTE what the call costs there: the callee
+// saves and restores its 112 callee-saved VGPRs through scratch memory on every call (ISA: 112 scratch_store / scratch_load_dword around the
+// body, ~2.5 us per pivot block by in-kernel stamps) -- the kernel-resource-usage remark of the KERNEL does not show the callee's frame.
+// chol128_regs has ONE call site and inlines it.
+__device__ __attribute__((noinline)) void pivot_block_16(double* S, double* Xd, double* rsd, double* pcol, double* lt, int* info, int64_t j0, int c,
+                                               int lane) {
+  pivot_block_16_body<false>(S, Xd, rsd, pcol, lt, info, j0, c, lane);
 }
 
 // element (i, j), i >= j, of X = L^-1 in its split storage
@@ -337,6 +348,105 @@ __device__ __forceinline__ double xval(const double* S, const double* Xd, int i,
   return ((i >> 4) == (j >> 4)) ? Xd[((i >> 4) * 16 + (i & 15)) * XS + (j & 15)] : S[j * LS + i];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pivot16: Cholesky of one 16x16 pivot block and its inverse by ONE wave (lane l mirrors row / column l & 15), written for a SHORT
+// dependent chain and FEW registers, so that it can be inlined at its single call site in chol128_regs. (The first form,
+// pivot_block_16, is a noinline function with two call sites: its call alone costs ~2.5 us per block -- 112 callee-saved VGPRs go
+// through scratch memory on every call -- and per pivot it waits for an LDS round trip in the middle of an 8-operation fp64 chain.)
+//   * Lane r keeps row r of the block in registers; column j (unscaled) is published through a 16-entry LDS line, as before -- but only
+//     the entries j+2.. are read from it, one iteration after they were written, so the LDS latency is off the recurrence.
+//   * The recurrence from pivot to pivot involves wave-uniform values only:  d_{j+1} = e - s^2 / d_j  with s = A[j+1][j] and
+//     e = A[j+1][j+1] as they stand before pivot j's update, both fetched by v_readlane while 1/d_j is still being refined. The
+//     chain per pivot is then fma -> rcp -> 2 Newton steps (6 dependent fp64 operations instead of 8 + LDS), everything else
+//     (the row updates, 1/sqrt(d), the publishing stores) fills the issue slots beside it.
+//   * Not positive definite (or NaN): the first failing leading minor is remembered in a register and flagged once, after the block;
+//     the sweep goes on with d = 1 so that everything stays finite (as before).
+// blk: the block inside S (row stride LS), holding the tile to factor, receives L_cc (zeros above the diagonal); Xdc: its slot in Xd;
+// rsdc: its 16 entries of rsd (1 / L_ii).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pivot16(double* blk, double* Xdc, double* rsdc, double* pcol, double* lt, int* info, int64_t row0, int lane,
+                                        bool stamp = false) {
+  const int r = lane & 15;
+  double a[16];
+  if (stamp) RC_T(24);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = (j <= r) ? blk[r * LS + j] : 0.0;
+  if (stamp) RC_T(25);
+  pcol[r] = a[0];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double dv = rl_d(a[0], 0);
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const double* line = pcol + (j & 1) * 16;
+    double ln[16];
+#pragma unroll
+    for (int q = (j + 2) >> 1; q < 8; ++q) {                     // column j, entries >= j + 2 (written one iteration ago)
+      const double2 v = *reinterpret_cast<const double2*>(line + 2 * q);
+      ln[2 * q] = v.x;
+      ln[2 * q + 1] = v.y;
+    }
+    const bool ok = dv > 0.0;
+    bad = (!ok && bad == 0) ? j + 1 : bad;
+    const double dd = ok ? dv : 1.0;
+    double rd = __builtin_amdgcn_rcp(dd);
+    rd = __builtin_fma(__builtin_fma(-dd, rd, 1.0), rd, rd);
+    rd = __builtin_fma(__builtin_fma(-dd, rd, 1.0), rd, rd);
+    const double tj = a[j] * rd;                                 // L[r][j] / sqrt(d) = A[r][j] / d
+    if (j < 15) {
+      const double s1 = rl_d(a[j], j + 1);                       // A[j+1][j]
+      const double e = rl_d(a[j + 1], j + 1);                    // A[j+1][j+1] before this pivot's update
+      dv = __builtin_fma(-(s1 * s1), rd, e);                     // the next pivot, wave-uniform
+      a[j + 1] = __builtin_fma(-tj, s1, a[j + 1]);
+      pcol[((j + 1) & 1) * 16 + r] = a[j + 1];                   // column j + 1 is complete: publish it
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int c2 = j + 2; c2 < 16; ++c2) a[c2] = __builtin_fma(-tj, ln[c2], a[c2]);
+    const double rs = rc_rsqrt(dd);
+    a[j] *= rs;                                                  // L[r][j]
+    if (lane == j) rsdc[j] = rs;
+  }
+  if (stamp) RC_T(26);
+  if (bad != 0 && lane == 0) atomicCAS(info, 0, (int)(row0 + bad));
+  // publish L_cc (rows from lanes 0..15) and its transpose, then invert it: lane j builds column j of X by forward substitution
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double v = (j <= r) ? a[j] : 0.0;
+      blk[r * LS + j] = v;
+      lt[j * 16 + r] = v;                                        // lt[k][i] = L[i][k]
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double x[16];
+  if (stamp) RC_T(27);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    double lk[16];
+#pragma unroll
+    for (int q = (k + 1) >> 1; q < 8; ++q) {
+      const double2 v = *reinterpret_cast<const double2*>(lt + k * 16 + 2 * q);
+      lk[2 * q] = v.x;
+      lk[2 * q + 1] = v.y;
+    }
+    x[k] *= rsdc[k];
+#pragma unroll
+    for (int i = k + 1; i < 16; ++i) x[i] = __builtin_fma(-lk[i], x[k], x[i]);
+  }
+  if (stamp) RC_T(28);
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Xdc[i * XS + r] = (i >= r) ? x[i] : 0.0;                    // Xd[c][i][j = r]
+  }
+  if (stamp) RC_T(30);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // chol128_regs: the 16-blocked Cholesky of the 128x128 block with the TRAILING MATRIX IN REGISTERS (k_diag2<MODE, true>).
@@ -366,7 +476,7 @@ __device__ __constant__ signed char rc_tile_owner[8][RC_REG_SLOTS][2] = {      /
     {{6, 6}, {6, 5}, {5, 3}, {6, 3}, {7, 3}},
     {{7, 7}, {7, 6}, {6, 4}, {7, 4}, {7, 5}}};
 
-__device__ __forceinline__ void chol128_regs(double* S, double* Xd, double* rsd, double* pcol, double* lt, int* info, int64_t j0) {
+__device__ __forceinline__ void chol128_regs(double* S, double* Xd, double* rsd, double* pcol, double* lt, int* info, int64_t j0, double* rv = nullptr) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   int rbs[RC_REG_SLOTS], cbs[RC_REG_SLOTS];
@@ -389,10 +499,27 @@ __device__ __forceinline__ void chol128_regs(double* S, double* Xd, double* rsd,
       for (int q = 0; q < 4; ++q) S[(16 * c + fr) * LS + 16 * c + 4 * q + fq] = acc[0][q];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      pivot_block_16(S, Xd, rsd, pcol, lt, info, j0, c, lane);
+      if (c == 0) RC_T(29);
+      // (an opaque zero per iteration: without it the compiler hoists the ~200 loop-invariant LDS addresses of the unrolled pivot
+      // sweep out of the c loop and keeps each in a register of its own -- 140 SGPRs spilled to VGPR lanes, 30 VGPRs to scratch)
+      int zero = 0;
+      asm volatile("" : "+s"(zero));
+      pivot16(S + (16 * c) * LS + 16 * c, Xd + c * 16 * XS, rsd + 16 * c, pcol + zero, lt + zero, info, j0 + 16 * c, lane + zero, c == 0);
+      if (c == 0) RC_T(31);
     }
     __syncthreads();                                  // X_cc (Xd[c]) and L_cc are visible
     RC_T(2 + 2 * c);
+    if (rv && wave == 0) {
+      // forward substitution of the right-hand side, a side job of wave 0 (which owns a single tile): w_c = X_cc r_c now, and the rows
+      // below -= L_{.,c} w_c once block column c is in S (after the next barrier). rv ends up holding w_j = L_jj^-1 rhs_j.
+      double sw = 0.0;
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sw = __builtin_fma(Xd[(c * 16 + lane) * XS + j], rv[16 * c + j], sw);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 16) rv[16 * c + lane] = sw;
+    }
     if (c == 7) break;
     double xa[4];
 #pragma unroll
@@ -410,6 +537,14 @@ __device__ __forceinline__ void chol128_regs(double* S, double* Xd, double* rsd,
     }
     __syncthreads();                                  // block column c of L is in S
     RC_T(3 + 2 * c);
+    if (rv && wave == 0) {
+      for (int row = 16 * (c + 1) + lane; row < 128; row += 64) {
+        double sw = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sw = __builtin_fma(S[row * LS + 16 * c + j], rv[16 * c + j], sw);
+        rv[row] -= sw;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < RC_REG_SLOTS; ++k) {          // trailing: slot 0 (the diagonal tile) first -- the next pivot wave has only that one
       if (rbs[k] >= 0 && cbs[k] > c) {
@@ -424,12 +559,13 @@ __device__ __forceinline__ void chol128_regs(double* S, double* Xd, double* rsd,
       }
     }
   }
+  if (rv) __syncthreads();                            // w_7 (wave 0) before anybody reads rv
 }
 
 // MODE 0: the whole job (factor, invert, w_j). MODE 1: factor only -- L_jj, log L_ii and the eight 16x16 diagonal-block inverses
 // (written into the diagonal 16-blocks of invL) -- which is all the NEXT chain step needs (k_prep1s solves the tile below by
 // substitution): the 128x128 inverse and w_j are 15 us of this kernel and come off the critical path. MODE 2: the rest, as a kernel
-// of its own on the column-work stream: reads L_jj and the diagonal-block inverses back, completes the right-hand side rows of
+// of its own on the column-work stream (MODE 3: the inversion alone, no right-hand side -- k_inv128_batched): reads L_jj and the diagonal-block inverses back, completes the right-hand side rows of
 // this block (rhs_j -= L(j, j-1) w_{j-1}: the block row the chain no longer updates), inverts, emits invL and w_j.
 template <int MODE, bool REG = false>
 __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
@@ -462,8 +598,8 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
       S[i * LS + j + 1] = (j + 1 <= i) ? v[q].y : 0.0;
     }
   }
-  if (MODE == 0 && t < 128) rv[t] = rhs[j0 + t];
-  if (MODE == 2) {
+  if ((MODE == 0 || (MODE == 1 && REG)) && t < 128) rv[t] = rhs[j0 + t];
+  if (MODE >= 2) {
     // the diagonal-block inverses of the factor-only kernel, and this block's right-hand side rows brought up to date with the tile
     // to the left (4 lanes per row, 16-byte loads all in flight)
     for (int e = t; e < 8 * 16 * 16; e += 512) {
@@ -472,7 +608,7 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
     }
     const int i = t >> 2, h4 = t & 3;
     double sacc = 0.0;
-    if (j0 > 0) {
+    if (MODE == 2 && j0 > 0) {
       const double* Trow = A + (j0 + i) * ld + (j0 - 128);
       const double* wprev = rhs + (j0 - 128);
       double2 tv[16], wv2[16];
@@ -486,15 +622,15 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
       sacc += __shfl_xor(sacc, 1);
       sacc += __shfl_xor(sacc, 2);
     }
-    if (h4 == 0) rv[i] = rhs[j0 + i] - sacc;
+    if (MODE == 2 && h4 == 0) rv[i] = rhs[j0 + i] - sacc;
   }
   __syncthreads();
   RC_T(1);
 
-  if (MODE != 2 && REG) {
-    chol128_regs(S, Xd, rsd, pcol, lt, info, j0);
+  if (MODE < 2 && REG) {
+    chol128_regs(S, Xd, rsd, pcol, lt, info, j0, MODE == 1 ? rv : nullptr);
   }
-  if (MODE != 2 && !REG) {
+  if (MODE < 2 && !REG) {
   // ------------------------------------------------------------------ blocked Cholesky
   // Iteration c: (a) trailing update with block column c-1 of the lower tiles (rb, cb), c <= cb <= rb -- tile (c, c) goes to
   // wave 0, which then factors that pivot block while the other waves finish the remaining tiles; (b) panel below the pivot block.
@@ -546,8 +682,8 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
     __syncthreads();
     RC_T(3 + 2 * c);
   }
-  }  // MODE != 2 && !REG
-  if (MODE != 2) {
+  }  // MODE < 2 && !REG
+  if (MODE < 2) {
   // L back to global (lower + diagonal, zeros above), log-diagonal
   for (int e = t; e < 128 * 64; e += 512) {
     const int i = e >> 6, j = (e & 63) * 2;
@@ -561,9 +697,10 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
       *reinterpret_cast<double2*>(invL + (16 * c + i) * 128 + 16 * c + j) =
           make_double2(Xd[(c * 16 + i) * XS + j], Xd[(c * 16 + i) * XS + j + 1]);
     }
+    if (REG && t < 128) rhs[j0 + t] = rv[t];         // w_j from the fused forward substitution of chol128_regs
     return;
   }
-  }  // MODE != 2
+  }  // MODE < 2
 
 #ifndef RC_DIAG2_NO_INVERSE
   // ------------------------------------------------------------------ inverse by recursive doubling
@@ -647,7 +784,7 @@ __device__ __forceinline__ void diag2_body(double* S, double* __restrict__ A, in
     const int i = e >> 6, j = (e & 63) * 2;
     *reinterpret_cast<double2*>(invL + i * 128 + j) = make_double2((j <= i) ? xval(S, Xd, i, j) : 0.0, (j + 1 <= i) ? xval(S, Xd, i, j + 1) : 0.0);
   }
-  {
+  if (MODE != 3) {
     const int i = t >> 2, h4 = t & 3;                // 4 threads per row
     double s = 0.0;
     for (int j = h4; j <= i; j += 4) s = __builtin_fma(xval(S, Xd, i, j), rv[j], s);
@@ -664,6 +801,14 @@ __global__ void __launch_bounds__(512) k_diag2(double* __restrict__ A, int64_t l
                                                double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
   extern __shared__ double S[];
   diag2_body<MODE, REG>(S, A, ld, invL, rhs, logdiag, info, j0);
+}
+
+// Every 128x128 inverse of the factor's diagonal blocks in ONE launch (block b: L_bb from A, its eight 16x16 diagonal-block inverses from
+// invdiag, the full inverse back into invdiag) -- after a factorisation whose chain never formed them (substitution-based solves), and
+// only when L^-1 is wanted at all: they are level 0 of the recursive-doubling inverse (rc_trtri).
+__global__ void __launch_bounds__(512) k_inv128_batched(double* __restrict__ A, int64_t ld, double* __restrict__ invdiag) {
+  extern __shared__ double S[];
+  diag2_body<3, false>(S, A, ld, invdiag + (size_t)blockIdx.x * 128 * 128, nullptr, nullptr, nullptr, (int64_t)blockIdx.x * 128);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -721,6 +866,20 @@ int rc_launch_diag_loop(rcgp_handle_s* h, unsigned long long base) {
   return 0;
 }
 
+int rc_launch_inv128_batched(rcgp_handle_s* h) {
+  const size_t lds = (size_t)(128 * LS + 8 * 16 * XS + 256 + 32 + 256) * sizeof(double);
+  static bool attr_set = false;                                // (device state; one device per process in practice, harmless to repeat)
+  if (!attr_set) {
+    RC_HIP(hipFuncSetAttribute((const void*)k_inv128_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  RcProfScope ps(h, RC_K_DIAG, 0.0, true);
+  RC_LAUNCH(k_inv128_batched, dim3((unsigned)(h->Np / 128)), dim3(512), lds, h->A, h->Np, h->invdiag);
+  RC_HIP(hipGetLastError());
+  h->invdiag_full = true;
+  return 0;
+}
+
 int rc_launch_diag(rcgp_handle_s* h, int64_t j, int mode) {
   RcProfScope ps(h, RC_K_DIAG, mode == 2 ? 0.0 : 128.0 * 128.0 * 128.0 / 3.0, true);
   double* inv = h->invdiag + (j / 128) * 128 * 128;
@@ -736,7 +895,7 @@ int rc_launch_diag(rcgp_handle_s* h, int64_t j, int mode) {
       RC_HIP(hipFuncSetAttribute((const void*)k_diag2<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       h->diag_attr_set = true;
     }
-    const bool reg = h->diag_variant == 3;
+    const bool reg = (h->diag_variant == 3 && h->prep_split != 3) || h->prep_split == 4;
     if (mode == 1) {
       if (reg) RC_LAUNCH((k_diag2<1, true>), dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
       else RC_LAUNCH(k_diag2<1>, dim3(1), dim3(512), lds, h->A, h->Np, inv, h->w, h->logdiag, h->info, j);
@@ -833,6 +992,11 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
   // late: the diagonal kernel only factors (k_diag2<1>); the 128x128 inverse and w_j follow on the column-work stream (k_diag2<2>, ahead
   // of the panel solve that needs them) and the chain's tile is solved by substitution (k_prep1s)
   const bool late = (h->prep_split == 3) && h->diag_variant != 1;
+  // subst: no 128x128 inverse on the chain at all -- the diagonal kernel factors only (register-resident core, w_j fused), the chain's
+  // tile and the column below are solved by blocked substitution (k_trsm_subst; the chain's instance also updates the next diagonal
+  // block), and the inverses the L^-1 stage starts from are formed afterwards in one batched launch (rc_trtri_advance)
+  const bool subst = (h->prep_split == 4) && h->diag_variant != 1;
+  h->invdiag_full = !subst;
   // t2p: the panel solve T2(j) waits for P(j)'s solved tile instead of D(j), so that D(j) carries no completion event (a dispatch that
   // carries one delays its successor on the stream by ~5 us: kernel trace)
   const bool t2p = h->t2_after_p && !late;
@@ -864,7 +1028,7 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
       if (below > 0) RC_HIP(hipStreamWaitValue64(B, h->sig_done, want, hipStreamWaitValueGte, 0xffffffffffffffffull));
     } else {
     if (ext && !t2p) h->launch_stop = eD;
-    if ((rc = rc_launch_diag(h, j, late ? 1 : 0)) || (rc = flush_stop(h))) return rc;
+    if ((rc = rc_launch_diag(h, j, (late || subst) ? 1 : 0)) || (rc = flush_stop(h))) return rc;
     }
     if (late) {
       if (!ext) RC_HIP(hipEventRecord(eD, C));
@@ -887,7 +1051,9 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
     if (eG_prev) RC_HIP(hipStreamWaitEvent(C, eG_prev, 0));
     if (first_of_panel && have_win && h->chain_ext < 2) RC_HIP(wait_window(C));   // P touches column j + 128 >= u0
     if (ext) h->launch_stop = eP;                                 // (with the split: taken by k_prep1 -- the column work needs the solved tile only)
-    if (late)
+    if (subst)
+      rc = rc_launch_chain_tile(h, P, h->A + (j + 128) * Np + (j + 128), Np, h->A + j * Np + j, inv, h->w + j + 128, h->w + j);
+    else if (late)
       rc = rc_launch_prep_subst(h, P, h->A + (j + 128) * Np + (j + 128), Np, h->A + j * Np + j, inv);
     else if (dloop)
       rc = (h->dloop == 2)
@@ -914,7 +1080,10 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
       hipEvent_t eT2, eFar;
       if ((rc = next_event(h, &eT2))) return rc;
       if (ext) h->launch_stop = eT2;
-      if ((rc = rc_launch_trsm_panel(h, P + 128 * Np, Np, inv, below - 128, h->w + j + 256, h->w + j)) || (rc = flush_stop(h))) return rc;
+      if ((rc = subst ? rc_launch_trsm_subst(h, P + 128 * Np, Np, h->A + j * Np + j, inv, below - 128, h->w + j + 256, h->w + j)
+                      : rc_launch_trsm_panel(h, P + 128 * Np, Np, inv, below - 128, h->w + j + 256, h->w + j)) ||
+          (rc = flush_stop(h)))
+        return rc;
       if (!ext) RC_HIP(hipEventRecord(eT2, B));
       const int64_t c0 = j + 128, nend = (c0 + 256 < cend) ? c0 + 256 : cend;
       // Catch-up mode (RCGP_CATCHUP = t, off by default) for the block columns taller than t blocks: instead of a K=128 far update at
@@ -990,7 +1159,9 @@ static int potrf_fine(rcgp_handle_s* h, bool overlap_inverse) {
         RC_HIP(hipEventRecord(ePanel, B));
       }
     } else if (below > 128) {
-      if ((rc = rc_launch_trsm_panel(h, P + 128 * Np, Np, inv, below - 128, h->w + j + 256, h->w + j))) return rc;
+      if ((rc = subst ? rc_launch_trsm_subst(h, P + 128 * Np, Np, h->A + j * Np + j, inv, below - 128, h->w + j + 256, h->w + j)
+                      : rc_launch_trsm_panel(h, P + 128 * Np, Np, inv, below - 128, h->w + j + 256, h->w + j)))
+        return rc;
       if (first_of_panel && have_win) RC_HIP(wait_window(B));
       RC_HIP(hipStreamWaitEvent(B, eP, 0));
       if (ext) h->launch_stop = eG;
@@ -1121,6 +1292,7 @@ int rc_potrf(rcgp_handle_s* h) {
     h->inverted = false;
     return 0;
   }
+  h->invdiag_full = true;                                          // (the coarse schedule's diagonal kernel forms every inverse)
   if ((rc = panel_factor(h, 0, NB < Np ? NB : Np))) return rc;
   for (int64_t J = 0; J + NB < Np; J += NB) {
     const int64_t Jend = J + NB;

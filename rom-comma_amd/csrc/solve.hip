@@ -47,6 +47,7 @@ int rc_trtri_advance(rcgp_handle_s* h, int64_t done_rows) {
   int rc;
   if (done_rows > Np) done_rows = Np;
   if (done_rows > h->tt_put_rows) {
+    if (!h->invdiag_full && (rc = rc_launch_inv128_batched(h))) return rc;
     RcProfScope ps(h, RC_K_MISC, 0.0);
     hipLaunchKernelGGL(k_put_diag, dim3((unsigned)((done_rows - h->tt_put_rows) / 128)), dim3(256), 0, h->launch, h->Linv, Np, h->invdiag,
                        h->tt_put_rows / 128);

@@ -8,6 +8,9 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from romcomma_amd import _lib                                      # noqa: E402
+import os
+if os.environ.get('RCGP_DEV_LIB'):
+    _lib.LIB_PATH = Path(os.environ['RCGP_DEV_LIB']).resolve()
 from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 N, M = 1024, 5
@@ -27,6 +30,7 @@ for c in range(8):
     names[4 + 2 * c] = f'trailing {c} + pivot {c + 1}'
 names.update({19: 'store L, logdiag', 20: 'inverse level 16', 21: 'inverse level 32', 22: 'inverse level 64', 23: 'store X, w'})
 print('pivot block 0 inside: load rows %.2f, 16 pivots %.2f, publish %.2f, inverse %.2f us' % tuple((t[k+1]-t[k])/100.0 for k in (24,25,26,27)))
+print('around pivot block 0: before call t=%.2f, entry %.2f, rows loaded %.2f, pivots done %.2f, published %.2f, inverse done %.2f, function end %.2f, returned %.2f' % tuple((t[k]-t[0])/100.0 for k in (29,24,25,26,27,28,30,31)))
 prev = 0.0
 for i in sorted(names):
     if t[i] == 0:
