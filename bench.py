@@ -27,6 +27,9 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (AMD spec). Sustained micro-benchmark: DESIGN.md.
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_MEASURED_TFMAS = 35.0  # fp64 vector FMA instructions/s (x1e12, all lanes) sustained in a register-only loop: 70 TFLOP/s measured
+SOBOL_VALU_OPS_PER_EXP = 24      # fp64 VALU instructions per exp of k_sobol_pairs: rc_exp (clamp 2, scale + rint 2, Cody-Waite 2, Horner 13,
+                                 # ldexp + convert 2) + the exponent's fma / add and the weighted accumulation (3)
 
 
 def all_slices(M):
@@ -50,19 +53,19 @@ def fold_schedule(rank, warmup, steps, n_folds):
 
 
 def pmc_traffic(N, M, kernel='k_grad'):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_c2.json, falling back to the
-    round-1 file; produced by tools/pmc_summary.py with the gfx950 FETCH_SIZE correction). Counters cannot be read inside this
-    process, so the number is the profiled one for the same workload and build; None for any other size."""
+    """(HBM bytes per launch of `kernel`, the file they come from): the committed rocprofv3 --pmc passes of the same workload and build
+    (profiles/r03_pmc_c2.json, falling back to earlier rounds; produced by tools/pmc_summary.py with the gfx950 FETCH_SIZE correction).
+    Counters cannot be read inside this process, so the number is NOT measured in this run; (None, None) for any other size."""
     if (N, M) != (16384, 10):
-        return None
-    for name in ('r02_pmc_c2.json', 'r01_pmc_c2.json'):
+        return None, None
+    for name in ('r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'):
         path = ROOT / 'profiles' / name
         if path.exists():
             try:
-                return float(json.load(open(path))[kernel]['hbm_bytes_per_launch'])
+                return float(json.load(open(path))[kernel]['hbm_bytes_per_launch']), f'profiles/{name}'
             except Exception:
                 continue
-    return None
+    return None, None
 
 
 def _blas_info():
@@ -76,17 +79,19 @@ def _blas_info():
         return int(os.cpu_count() or 1), 'unknown'
 
 
-def _cpu_times(o, N, M, sobol_rows, fit=False):
-    """Wall times of the oracle on this host at one configuration: one LML+gradient evaluation fully timed at (N, M); the 3M+1 Sobol
-    quadratic forms on a stripe of `sobol_rows` rows against all N columns, scaled by N / sobol_rows (the work per row is uniform);
-    with `fit`, a whole L-BFGS-B fit as well (small sizes only)."""
-    X, y = o.synthetic_fold(N, M)
-    ell, var, _ = o.bench_hyper(M)
-    noise = 1e-2
-    t0 = time.perf_counter()
-    o.lml_and_grad_blas(X, y, ell, var, noise)
-    t_eval = time.perf_counter() - t0
-    out = {'N': N, 'M': M, 'evaluation_s': t_eval}
+def _cpu_times(o, N, M, sobol_rows, fit=False, fold=None, theta=None, samples=1):
+    """Wall times of the oracle on this host at one configuration: the LML+gradient evaluation fully timed at (N, M) (`samples` times: all
+    reported, the fastest used); the 3M+1 Sobol quadratic forms on a stripe of `sobol_rows` rows against all N columns, scaled by
+    N / sobol_rows (the work per row is uniform); with `fit`, a whole L-BFGS-B fit as well (small sizes only). `fold` = (X, y) and
+    `theta` = (ell, var, noise) default to the seeded fold 0 and the fixed benchmark hyper-parameters."""
+    X, y = o.synthetic_fold(N, M) if fold is None else fold
+    ell, var, noise = (*o.bench_hyper(M)[:2], 1e-2) if theta is None else theta
+    times, value = [], None
+    for _ in range(max(samples, 1)):
+        t0 = time.perf_counter()
+        value = o.lml_and_grad_blas(X, y, ell, var, noise)
+        times.append(time.perf_counter() - t0)
+    out = {'N': N, 'M': M, 'evaluation_s': min(times), 'evaluation_samples_s': times}
     if fit:
         t0 = time.perf_counter()
         res = o.fit(X, y, 5.0 * np.ones(M))
@@ -99,29 +104,41 @@ def _cpu_times(o, N, M, sobol_rows, fit=False):
     o.sobol_V_pair(X, g[0], g[0], phi[0], phi[0], o.all_slices(M), rows=(0, rows))
     out['sobol_s'] = (time.perf_counter() - t0) * N / rows
     out['sobol_sample_rows'] = rows
-    return out
+    return out, value
 
 
-def cpu_baseline(N, M, nfev_per_step):
+def cpu_baseline(N, M, nfev_per_step, fold=None, theta=None, gpu_value=None):
     """The oracle (NumPy/SciPy fp64, `oracle/gp_oracle.py`: LAPACK potrf + potri, BLAS-3 gradient sums) timed on this box's host
-    cores AT the benchmark's configuration: one real LML+gradient evaluation at (N, M), times the evaluation count the GPU fit
-    needed (the same SciPy driver would take the same path), plus the Sobol forms from a row stripe. SURVEY.md 8d's C0 and C1
-    are timed beside it. A reported baseline, not the target; conservative: GPflow autodiff does more work per evaluation."""
+    cores AT the benchmark's configuration, on the fold of the last timed step and at the hyper-parameters the GPU fit ended on: one
+    real LML+gradient evaluation at (N, M) (two samples at C2), times the evaluation count the GPU fit needed (the same SciPy driver
+    would take the same path), plus the Sobol forms from a row stripe. The same call is the full-size parity check: its LML and
+    gradient against the GPU's at that point (`parity_at_config`). SURVEY.md 8d's C0 and C1 are timed beside it. A reported baseline,
+    not the target; conservative: GPflow autodiff does more work per evaluation."""
     from oracle import gp_oracle as o
     cores, vendor = _blas_info()
     o.lml_and_grad_blas(*o.synthetic_fold(512, M), *o.bench_hyper(M)[:2], 1e-2)      # BLAS threads up, pages touched: not timed
     configs = {}
-    if (N, M) == (16384, 10):
-        configs['C0'] = _cpu_times(o, 256, 3, 256, fit=True)
-        configs['C1'] = _cpu_times(o, 8192, 5, 256)
-    main = _cpu_times(o, N, M, 256 if N > 4096 else N)
-    configs['C2' if (N, M) == (16384, 10) else 'bench'] = main
+    is_c2 = (N, M) == (16384, 10)
+    if is_c2:
+        configs['C0'] = _cpu_times(o, 256, 3, 256, fit=True)[0]
+        configs['C1'] = _cpu_times(o, 8192, 5, 256)[0]
+    main, (lml_cpu, grad_cpu) = _cpu_times(o, N, M, 256 if N > 4096 else N, fold=fold, theta=theta, samples=2 if is_c2 else 1)
+    configs['C2' if is_c2 else 'bench'] = main
     t_full = nfev_per_step * main['evaluation_s'] + main['sobol_s']
-    return {'value': N / t_full, 'unit': 'train-points/s', 'cores': cores, 'kind': 'port', 'blas': vendor,
-            'sample': f'oracle.lml_and_grad_blas timed once at the full N={N}, M={M} ({main["evaluation_s"]:.2f} s) x {nfev_per_step:.1f} evaluations per '
-                      f'fit (the GPU fit\'s count) + {3 * M + 1} Sobol quadratic forms timed on a {main["sobol_sample_rows"]}-row stripe x N/{main["sobol_sample_rows"]} '
-                      f'({main["sobol_s"]:.1f} s); fit+Sobol wall time {t_full:.1f} s on {cores} threads ({vendor})',
-            'configs': configs}
+    out = {'value': N / t_full, 'unit': 'train-points/s', 'cores': cores, 'kind': 'port', 'blas': vendor,
+           'sample': f'oracle.lml_and_grad_blas at the full N={N}, M={M} on the last timed fold at the GPU\'s fitted hyper-parameters, '
+                     f'{len(main["evaluation_samples_s"])} sample(s) {["%.2f" % t for t in main["evaluation_samples_s"]]} s, fastest x {nfev_per_step:.1f} evaluations per '
+                     f'fit (the GPU fit\'s count) + {3 * M + 1} Sobol quadratic forms timed on a {main["sobol_sample_rows"]}-row stripe x N/{main["sobol_sample_rows"]} '
+                     f'({main["sobol_s"]:.1f} s); fit+Sobol wall time {t_full:.1f} s on {cores} threads ({vendor})',
+           'configs': configs}
+    if gpu_value is not None:
+        lml_gpu, grad_gpu = gpu_value
+        scale = float(np.max(np.abs(grad_cpu)))
+        out['parity_at_config'] = {'lml_gpu': float(lml_gpu), 'lml_cpu': float(lml_cpu), 'rel': abs(float(lml_gpu) - float(lml_cpu)) / abs(float(lml_cpu)),
+                                   'grad_max_rel': float(np.max(np.abs(np.asarray(grad_gpu) - grad_cpu)) / scale),
+                                   'at': 'the last timed fold, the hyper-parameters its GPU fit converged to; gradient w.r.t. (lengthscales, variance, noise), '
+                                         'error relative to the largest component'}
+    return out
 
 
 def main():
@@ -273,6 +290,9 @@ def main():
         family = (flops + grad_flops) / ((ms_gemm + ms_grad) * 1e-3) / 1e12 if ms_gemm + ms_grad > 0 else 0.0
         nfev = int(last['fit']['nfev'])
         nfev_total = int(counter['nfev'])                    # rank 0's L-BFGS-B evaluations over the timed steps
+        eval_ms = 1e3 * counter['lib_s'] / max(nfev_total, 1)
+        traffic, traffic_file = pmc_traffic(N, M)
+        sobol_texp = sob_exps / (ms_sob * 1e-3) / 1e12 if ms_sob > 0 else 0.0
         out = {
             'metric': 'GP-fit+Sobol train-points/s (wall-time per fit+Sobol in ms_per_step), fp64',
             'value': world * N * args.steps / elapsed,
@@ -289,10 +309,17 @@ def main():
                        'ms_per_step_host_only': 1e3 * (elapsed - counter['lib_s'] - counter['sobol_s']) / args.steps, 'parallelism': f'{args.shard[:-1]}-per-gpu x{world}',
                        'log_marginal': last['fit']['log_marginal']},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic(N, M),
-                         'kernel': 'k_grad (K^-1 = L^-T L^-1 on fp64 MFMA fused with the LML-gradient reduction)',
+                         'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                         'traffic_source': (f'{traffic_file}: rocprofv3 --pmc pass of the same workload and build, NOT measured in this run' if traffic_file else None),
+                         'kernel': 'k_grad (K^-1 = L^-T L^-1 on fp64 MFMA fused with the LML-gradient reduction): the largest single launch, one per '
+                                   'evaluation. By SUMMED time the K = NB update kernels of the Cholesky (k_gemm_nt_sub + k_syrk_lower, many launches on '
+                                   'several streams) are the larger family: stages.mfma_gemm_family, profiles/r03_*_kernel_stats.csv',
                          'launches': int(n_grad), 'avg_launch_ms': ms_grad / max(n_grad, 1),
-                         'algorithmic_flops_per_launch': grad_flops / max(n_grad, 1)},
+                         'algorithmic_flops_per_launch': grad_flops / max(n_grad, 1),
+                         'evaluation': {'algorithmic_flops': float(N) ** 3, 'ms': eval_ms, 'achieved': float(N) ** 3 / (eval_ms * 1e-3) / 1e12,
+                                        'frac': float(N) ** 3 / (eval_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                        'note': 'one LML + gradient evaluation = Gram + Cholesky + L^-1 + fused K^-1/gradient = N^3 flops; ms = wall time '
+                                                'inside the library calls of the timed fits / evaluations (host wait included)'}},
             'stages': {
                 'gram': {'bound': 'hbm', 'achieved_GBs': gram_bytes / (ms_gram * 1e-3) / 1e9 if ms_gram > 0 else 0.0, 'peak_GBs': HBM_PEAK_GBS,
                          'frac': (gram_bytes / (ms_gram * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_gram > 0 else 0.0,
@@ -301,7 +328,9 @@ def main():
                              'frac': N ** 3 / 3.0 / (min(chol_ms) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                              'note': 'stand-alone rcgp_stage_potrf (incl. w = L^-1 y) after the timed region, best of 3, host wall clock around a sync'},
                 'diag_blocks': {'launches': int(n_diag), 'total_ms': ms_diag},
-                'sobol': {'launches': int(n_sob), 'total_ms': ms_sob, 'Gexp_per_s': sob_exps / (ms_sob * 1e-3) / 1e9 if ms_sob > 0 else 0.0},
+                'sobol': {'bound': 'fp64 VALU (exp)', 'launches': int(n_sob), 'total_ms': ms_sob, 'Gexp_per_s': 1e3 * sobol_texp,
+                          'valu_ops_per_exp': SOBOL_VALU_OPS_PER_EXP, 'measured_valu_peak_Tops': FP64_VALU_MEASURED_TFMAS,
+                          'frac_of_measured_valu_peak': sobol_texp * SOBOL_VALU_OPS_PER_EXP / FP64_VALU_MEASURED_TFMAS},
                 'mfma_gemm_family': {'launches': int(n_gemm + n_grad), 'summed_launch_ms': ms_gemm + ms_grad,
                                      'TFLOPs_over_summed_launch_time': family,
                                      'note': 'Cholesky / L^-1 / K^-1 kernels; the Cholesky runs them on several streams, so summed launch time exceeds wall time'},
@@ -311,7 +340,13 @@ def main():
         out['roofline']['stages'] = {k: {kk: vv for kk, vv in out['stages'][k].items() if kk in ('bound', 'frac', 'achieved_GBs', 'achieved_TFLOPs', 'ms', 'avg_launch_ms')}
                                      for k in ('gram', 'cholesky')}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(N, M, nfev_total / max(args.steps, 1))
+            fit = last['fit']
+            theta = (np.asarray(fit['lengthscales'], dtype=float), float(fit['variance']), float(fit['noise']))
+            gp.set_hyper(*theta)
+            gpu_value = gp.lml_grad()
+            fold = synthetic_cv_fold(N, M, k=units[-1], K=K_folds) if args.shard == 'folds' else (X, Y[:, rank])
+            out['cpu_baseline'] = cpu_baseline(N, M, nfev_total / max(args.steps, 1), fold=fold, theta=theta, gpu_value=gpu_value)
+            out['parity_at_config'] = out['cpu_baseline'].get('parity_at_config')
         print(json.dumps(out), flush=True)
     for h in handles.values():
         h.close()

@@ -25,30 +25,21 @@ RC_API int rcgp_device_count(void) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// One set of streams per device (and per value of the two knobs that shape them), shared by every handle of the process on that
-// device and kept for the life of the process. Every stream is a hardware queue that the runtime keeps anyway, and the
-// multi-stream Cholesky slows down by a quarter once a few more queues than its own six exist (three handles alive at once: 34 ->
-// 43 ms at C2; DESIGN.md "tried and rejected"). Handles are used one call at a time by their owner, so sharing the streams only
-// orders the work of different handles of one device behind each other. The set is kept until process exit: tearing six hardware
-// queues down and building them again for every handle is needless churn in the runtime. (Round 1 did that, in an order the HIP
-// contract does not cover -- only the main stream joined, events destroyed ahead of the streams that carried them, queues
-// destroyed while their last marker packets could still be outstanding -- and the GPU test suite stalled twice; DESIGN.md section 6
-// lists what was wrong. Every teardown below now joins ALL streams of the set first.)
+// ONE set of five streams per device, created by the first rcgp_create on that device and shared by every handle of the process on
+// it until process exit -- whatever the environment says later. Every stream is a hardware queue that the runtime keeps anyway, and the
+// multi-stream Cholesky slows down by a quarter once a few more queues than its own exist (three handles with streams of their own:
+// 34 -> 43 ms at C2; idle queues created BETWEEN the library's: 33 -> 75 ms; DESIGN.md section 4, "stream placement"). Handles are used
+// one call at a time by their owner, so sharing the streams only orders the work of different handles of one device behind each
+// other. Creation order is fixed (main, chain, column work, far updates, bulk): with it the two streams that carry long K = NB
+// kernels share a dispatch pipe and the chain's three have one each, the best of the 20 orders measured in round 2.
+// Teardown joins ALL streams of the set before anything is released (round 1 did not, and stalled).
 // ---------------------------------------------------------------------------------------------------------------------
 struct RcDeviceStreams {
-  hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr, stream5 = nullptr, stream6 = nullptr;
-  std::vector<hipStream_t> pads;       // RCGP_STREAM_PAD experiment
+  hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream5 = nullptr, stream6 = nullptr;
   int refs = 0;
 };
 static std::mutex g_streams_mutex;
-static std::map<std::tuple<int, int, int>, RcDeviceStreams> g_streams;      // (device, RCGP_RESERVE_CUS, RCGP_RESERVE_CUS_INV)
-
-static std::tuple<int, int, int> streams_key(int device) {
-  int reserve = RC_RESERVE_CUS_DEFAULT, reserve_inv = 128;
-  if (const char* e = getenv("RCGP_RESERVE_CUS")) reserve = atoi(e);
-  if (const char* e = getenv("RCGP_RESERVE_CUS_INV")) reserve_inv = atoi(e);
-  return std::make_tuple(device, reserve, reserve_inv);
-}
+static std::map<int, RcDeviceStreams> g_streams;      // by device
 
 // At process exit the sets are destroyed by this handler, registered with the first set: it runs before the HIP runtime (and a
 // profiler's intercept layer) are torn down, which handlers registered at load time outlive -- streams left to the runtime's own
@@ -57,14 +48,12 @@ static void destroy_stream_sets() {
   std::lock_guard<std::mutex> lock(g_streams_mutex);
   for (auto& kv : g_streams) {
     RcDeviceStreams& ds = kv.second;
-    if (hipSetDevice(std::get<0>(kv.first)) != hipSuccess) continue;
-    hipStream_t* all[] = {&ds.stream4, &ds.stream6, &ds.stream5, &ds.stream3, &ds.stream2, &ds.stream};
+    if (hipSetDevice(kv.first) != hipSuccess) continue;
+    hipStream_t* all[] = {&ds.stream6, &ds.stream5, &ds.stream3, &ds.stream2, &ds.stream};
     for (auto sp : all)                                   // every queue idle before the first one goes
       if (*sp) (void)hipStreamSynchronize(*sp);
     for (auto sp : all)
       if (*sp) { (void)hipStreamDestroy(*sp); *sp = nullptr; }
-    for (auto p : ds.pads) (void)hipStreamDestroy(p);
-    ds.pads.clear();
   }
 }
 
@@ -72,7 +61,7 @@ static void destroy_stream_sets() {
 // so after a call that returned normally the main stream alone would do; a call that failed half-way (a HIP error between two
 // launches) leaves the side streams running on their own, and the handle's buffers and events must outlive that work.
 static void join_streams(rcgp_handle_s* h) {
-  hipStream_t all[] = {h->stream2, h->stream5, h->stream6, h->stream3, h->stream4, h->stream};
+  hipStream_t all[] = {h->stream2, h->stream5, h->stream6, h->stream3, h->stream};
   for (auto s : all)
     if (s) (void)hipStreamSynchronize(s);
 }
@@ -80,23 +69,19 @@ static void join_streams(rcgp_handle_s* h) {
 static void release_streams(rcgp_handle_s* h) {
   if (!h->streams_acquired) return;
   std::lock_guard<std::mutex> lock(g_streams_mutex);
-  --g_streams[h->streams_key].refs;                    // bookkeeping only: the set stays
-  h->stream = h->stream2 = h->stream3 = h->stream4 = h->stream5 = h->stream6 = nullptr;
+  --g_streams[h->device].refs;                         // bookkeeping only: the set stays
+  h->stream = h->stream2 = h->stream3 = h->stream5 = h->stream6 = nullptr;
   h->streams_acquired = false;
 }
 
 static void free_all(rcgp_handle_s* h) {
   double** bufs[] = {&h->X, &h->Z, &h->sq, &h->y, &h->w, &h->alpha, &h->A, &h->Linv, &h->S, &h->invdiag, &h->logdiag, &h->partial,
-                     &h->scal, &h->ell_d, &h->tile_tmp, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob, &h->gV, &h->gC};
+                     &h->scal, &h->ell_d, &h->Xs, &h->Zs, &h->sqs, &h->KsT, &h->pmean, &h->pvar, &h->sob, &h->gV, &h->gC};
   for (auto b : bufs)
     if (*b) { hipFree(*b); *b = nullptr; }
   h->info = nullptr;                                       // (inside scal)
   h->FS_d = nullptr;                                       // (inside ell_d's allocation)
   if (h->pin) { (void)hipHostFree(h->pin); h->pin = nullptr; }
-  if (h->sig_flag) { (void)hipFree(h->sig_flag); h->sig_flag = nullptr; }
-  if (h->sig_ready) { (void)hipFree(h->sig_ready); h->sig_ready = nullptr; }
-  if (h->sig_done) { (void)hipFree(h->sig_done); h->sig_done = nullptr; }
-  if (h->heavy_ctr) { (void)hipFree(h->heavy_ctr); h->heavy_ctr = nullptr; }
   if (h->ev_hyper) { (void)hipEventDestroy(h->ev_hyper); h->ev_hyper = nullptr; }
   for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
   h->prof_events.clear();
@@ -104,7 +89,6 @@ static void free_all(rcgp_handle_s* h) {
   h->event_pool.clear();
   for (auto& e : h->la_events) (void)hipEventDestroy(e);
   h->la_events.clear();
-  if (h->ev_inv) { (void)hipEventDestroy(h->ev_inv); h->ev_inv = nullptr; }
   release_streams(h);
 }
 
@@ -131,100 +115,63 @@ static int upload_targets(rcgp_handle_s* h, const double* Y) {
   return 0;
 }
 
-// The six streams of a device. How the runtime places them on hardware queues depends on the ORDER in which they are created and on
-// every other stream the process has made before and between them ("stream placement": 32.7 ms to 75 ms for the same
-// C2 factorisation), so the order is fixed here and two diagnostic knobs can change it: RCGP_STREAM_ORDER (the digits of the streams in
-// creation order, default "025634" = main, chain, column work, far updates, bulk, spare; leaving out 4 leaves the spare stream out) and
-// RCGP_STREAM_PAD (a:b:c:d:e:f = idle streams created before the 1st ... 6th of them).
 static int create_streams(rcgp_handle_s* h, RcDeviceStreams& ds) {
-  // RCGP_LOWPRIO: 1 = the bulk-update stream at the LOWEST priority, 2 = the main stream (window pieces) as well
-  int lowprio = 0;
-  if (const char* e = getenv("RCGP_LOWPRIO")) lowprio = atoi(e);
   int lo = 0, hi = 0;
   RC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));            // hi is the numerically lowest = highest priority
-  int padn[6] = {0, 0, 0, 0, 0, 0};
-  if (const char* e = getenv("RCGP_STREAM_PAD")) sscanf(e, "%d:%d:%d:%d:%d:%d", &padn[0], &padn[1], &padn[2], &padn[3], &padn[4], &padn[5]);
-  static void* pad_word = nullptr;
-  auto pad = [&](int count, int prio) -> int {
-    for (int i = 0; i < count; ++i) {
-      hipStream_t s;
-      if (!pad_word) RC_HIP(hipMalloc(&pad_word, 64));
-      RC_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
-      RC_HIP(hipMemsetAsync(pad_word, 0, 4, s));
-      RC_HIP(hipStreamSynchronize(s));
-      ds.pads.push_back(s);
-    }
-    return 0;
-  };
-  // The bulk-update stream may be confined to every CU except the first RCGP_RESERVE_CUS, which then stay free for the panel chain.
-  // Default 0 = no mask: with the chain kernels of this build a reserve no longer pays at C2 (33.5 vs 33.4 ms with 24 CUs held back)
-  // and costs 2.4 % at N = 28672 (142.3 vs 138.9 ms).
-  int reserve = RC_RESERVE_CUS_DEFAULT, reserve_inv = 128;
-  if (const char* e = getenv("RCGP_RESERVE_CUS")) reserve = atoi(e);
-  if (const char* e = getenv("RCGP_RESERVE_CUS_INV")) reserve_inv = atoi(e);
-  hipDeviceProp_t prop;
-  RC_HIP(hipGetDeviceProperties(&prop, h->device));
-  const int ncu = prop.multiProcessorCount;
-  bool masked3 = false;
-  const bool reserve_all = getenv("RCGP_RESERVE_ALL") && getenv("RCGP_RESERVE_ALL")[0] != '0';
-  auto create_masked = [&](hipStream_t* out, int first_cu) -> bool {   // every CU from first_cu on
-    if (first_cu <= 0 || first_cu >= ncu) return false;
-    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-    for (int cu = first_cu; cu < ncu; ++cu) mask[cu / 32] |= (1u << (cu % 32));
-    if (hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()) == hipSuccess) return true;
-    (void)hipGetLastError();
-    return false;
-  };
-  auto create_one = [&](char which) -> int {
-    switch (which) {
-      case '0':
-        if (lowprio >= 2) RC_HIP(hipStreamCreateWithPriority(&ds.stream, hipStreamNonBlocking, lo));
-        else RC_HIP(hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking));
-        break;
-      case '2': RC_HIP(hipStreamCreateWithPriority(&ds.stream2, hipStreamNonBlocking, hi)); break;
-      // RCGP_RESERVE_ALL=1: the column-work streams stay off the reserved CUs as well (with RCGP_PIECES_ON_BULK=1 the chain stream is then
-      // the only one that can reach them); a CU-masked stream has no priority
-      case '5':
-        if (!(reserve_all && create_masked(&ds.stream5, reserve))) RC_HIP(hipStreamCreateWithPriority(&ds.stream5, hipStreamNonBlocking, hi));
-        break;
-      case '6':
-        if (!(reserve_all && create_masked(&ds.stream6, reserve))) RC_HIP(hipStreamCreateWithPriority(&ds.stream6, hipStreamNonBlocking, hi));
-        break;
-      case '3':
-        masked3 = create_masked(&ds.stream3, reserve);
-        if (getenv("RCGP_VERBOSE")) fprintf(stderr, "[rcgp] %d CUs, reserve %d, CU-masked bulk stream: %s\n", ncu, reserve, masked3 ? "yes" : "no");
-        if (!masked3) {
-          if (lowprio >= 1) RC_HIP(hipStreamCreateWithPriority(&ds.stream3, hipStreamNonBlocking, lo));
-          else RC_HIP(hipStreamCreateWithFlags(&ds.stream3, hipStreamNonBlocking));
-        }
-        break;
-      case '4':
-        // (the stream of the rejected L^-1 overlap mode; beside a CU-masked bulk stream it is confined to the upper part of the chip, so
-        // that its long tiles leave CUs to the panel chain's GEMMs)
-        if (!(masked3 && create_masked(&ds.stream4, reserve_inv))) RC_HIP(hipStreamCreateWithFlags(&ds.stream4, hipStreamNonBlocking));
-        break;
-      default: return -1;
-    }
-    return 0;
-  };
-  const char* order = getenv("RCGP_STREAM_ORDER");
-  if (!order || !*order) order = "025634";
-  int k = 0;
-  for (const char* c = order; *c; ++c, ++k) {
-    const bool high = (*c == '2' || *c == '5' || *c == '6');
-    hipStream_t* slot[7] = {&ds.stream, nullptr, &ds.stream2, &ds.stream3, &ds.stream4, &ds.stream5, &ds.stream6};
-    if (*c < '0' || *c > '6' || !slot[*c - '0'] || *slot[*c - '0']) {                   // unknown or repeated
-      h->err = "RCGP_STREAM_ORDER: a permutation of the digits 0 2 5 6 3 (and optionally 4) is expected";
-      return -1;
-    }
-    if (k < 6 && pad(padn[k], high ? hi : 0)) return -1;
-    if (create_one(*c)) return -1;
-  }
-  if (!ds.stream || !ds.stream2 || !ds.stream3 || !ds.stream5 || !ds.stream6) {            // only the spare stream may be left out
-    h->err = "RCGP_STREAM_ORDER: only stream 4 may be left out";
-    return -1;
-  }
+  RC_HIP(hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking));
+  RC_HIP(hipStreamCreateWithPriority(&ds.stream2, hipStreamNonBlocking, hi));
+  RC_HIP(hipStreamCreateWithPriority(&ds.stream5, hipStreamNonBlocking, hi));
+  RC_HIP(hipStreamCreateWithPriority(&ds.stream6, hipStreamNonBlocking, hi));
+  RC_HIP(hipStreamCreateWithFlags(&ds.stream3, hipStreamNonBlocking));
   return 0;
+}
+
+// The schedule's run-time knobs: environment variables, read ONCE per process (at the first rcgp_create) -- a value changed later is
+// ignored with a message, so that two handles of one process can never run different schedules on the shared streams.
+struct RcKnobs {
+  bool read = false;
+  bool lookahead = true, fine = true;
+  int64_t nb = RC_NB_OUTER;
+  int depth = 2, ext = 4;
+  std::string seen;                                    // the five values as first read, to recognise a later change
+};
+static RcKnobs g_knobs;
+
+static std::string knob_string() {
+  std::string out;
+  for (const char* name : {"RCGP_LOOKAHEAD", "RCGP_FINE", "RCGP_NB", "RCGP_DEPTH", "RCGP_EXT"}) {
+    const char* e = getenv(name);
+    out += std::string(name) + "=" + (e ? e : "") + ";";
+  }
+  return out;
+}
+
+static void read_knobs_once() {                          // (under g_streams_mutex)
+  const std::string now = knob_string();
+  if (g_knobs.read) {
+    if (now != g_knobs.seen) {
+      static bool warned = false;
+      if (!warned) fprintf(stderr, "[rcgp] RCGP_* knobs changed after the first rcgp_create of this process: ignored (%s in force)\n", g_knobs.seen.c_str());
+      warned = true;
+    }
+    return;
+  }
+  g_knobs.read = true;
+  g_knobs.seen = now;
+  if (const char* e = getenv("RCGP_LOOKAHEAD")) g_knobs.lookahead = (e[0] != '0');   // 0 = strictly sequential potrf
+  if (const char* e = getenv("RCGP_FINE")) g_knobs.fine = (e[0] != '0');             // 0 = one stream per panel chain (D, T, G in order)
+  if (const char* e = getenv("RCGP_EXT")) {
+    const int x = atoi(e);
+    if (x >= 1 && x <= 16) g_knobs.ext = x;
+  }
+  if (const char* e = getenv("RCGP_DEPTH")) {
+    const int x = atoi(e);
+    if (x >= 1 && x <= 64) g_knobs.depth = x;
+  }
+  if (const char* e = getenv("RCGP_NB")) {
+    const int64_t nb = atoll(e);
+    if (nb >= 128 && nb <= 4096 && nb % 128 == 0) g_knobs.nb = nb;
+  }
 }
 
 static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
@@ -233,14 +180,14 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
   RC_HIP(hipSetDevice(h->device));
   {
     std::lock_guard<std::mutex> lock(g_streams_mutex);
-    h->streams_key = streams_key(h->device);
-    RcDeviceStreams& ds = g_streams[h->streams_key];
+    read_knobs_once();
+    RcDeviceStreams& ds = g_streams[h->device];
     if (!ds.stream) {
       static bool registered = false;
       if (!registered) { atexit(destroy_stream_sets); registered = true; }
       int rcs = create_streams(h, ds);
       if (rcs) {                                        // leave no half-built set behind
-        hipStream_t* all[] = {&ds.stream4, &ds.stream6, &ds.stream5, &ds.stream3, &ds.stream2, &ds.stream};
+        hipStream_t* all[] = {&ds.stream6, &ds.stream5, &ds.stream3, &ds.stream2, &ds.stream};
         for (auto sp : all)
           if (*sp) { (void)hipStreamDestroy(*sp); *sp = nullptr; }
         return rcs;
@@ -248,69 +195,14 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     }
     ++ds.refs;
     h->streams_acquired = true;
-    h->stream = ds.stream; h->stream2 = ds.stream2; h->stream3 = ds.stream3; h->stream4 = ds.stream4; h->stream5 = ds.stream5;
-    h->stream6 = ds.stream6;
+    h->stream = ds.stream; h->stream2 = ds.stream2; h->stream3 = ds.stream3; h->stream5 = ds.stream5; h->stream6 = ds.stream6;
+    h->lookahead = g_knobs.lookahead;
+    h->fine_chain = g_knobs.fine;
+    h->nb_outer = g_knobs.nb;
+    h->chain_depth = g_knobs.depth;
+    h->chain_ext = g_knobs.ext;
   }
-  RC_HIP(hipEventCreateWithFlags(&h->ev_inv, hipEventDisableTiming));
   h->launch = h->stream;
-  if (const char* e = getenv("RCGP_DIAG")) h->diag_variant = atoi(e);
-  if (const char* e = getenv("RCGP_OVERLAP_INVERSE")) h->overlap_ok = (e[0] != '0') && h->stream4;   // (the device's stream set may predate the knob)
-  if (const char* e = getenv("RCGP_LOOKAHEAD")) h->lookahead = (e[0] != '0');     // tuning knob: 0 = strictly sequential potrf
-  if (const char* e = getenv("RCGP_FINE")) h->fine_chain = (e[0] != '0');         // 0 = one stream per panel chain (D, T, G in order)
-  if (const char* e = getenv("RCGP_EXT")) {
-    const int x = atoi(e);
-    if (x >= 1 && x <= 16) h->chain_ext = x;
-  }
-  if (const char* e = getenv("RCGP_EXTEV")) h->ext_events = (e[0] != '0');
-  if (const char* e = getenv("RCGP_SPLIT")) h->chain_split = (e[0] != '0');
-  if (const char* e = getenv("RCGP_PSPLIT")) h->prep_split = atoi(e);
-  if (const char* e = getenv("RCGP_SHORTK")) h->short_k = (e[0] != '0');
-  if (const char* e = getenv("RCGP_GRAD_ORDER")) h->grad_order = atoi(e);
-  if (const char* e = getenv("RCGP_T2WAIT")) h->t2_after_p = (e[0] != '0');
-  if (const char* e = getenv("RCGP_BULK_AFTER_PIECE")) h->bulk_after_piece = (e[0] != '0');
-  if (const char* e = getenv("RCGP_PIECES_ON_BULK")) h->pieces_on_bulk = (e[0] != '0');
-  if (const char* e = getenv("RCGP_CATCHUP")) h->catchup_blocks = atoi(e) > 0 ? atoi(e) : 0;
-  if (const char* e = getenv("RCGP_HEAVY")) h->heavy_mode = atoi(e);
-  if (const char* e = getenv("RCGP_DLOOP")) h->dloop = atoi(e);
-  if (const char* e = getenv("RCGP_PREP_SMALL")) h->prep_small = (e[0] != '0');
-  if (h->dloop) {
-    int can = 0;
-    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess || !can ||
-        hipExtMallocWithFlags((void**)&h->sig_ready, sizeof(uint64_t), hipMallocSignalMemory) != hipSuccess ||
-        hipExtMallocWithFlags((void**)&h->sig_done, sizeof(uint64_t), hipMallocSignalMemory) != hipSuccess) {
-      (void)hipGetLastError();
-      h->dloop = 0;
-    } else {
-      RC_HIP(hipMemsetAsync(h->sig_ready, 0, sizeof(uint64_t), h->stream));
-      RC_HIP(hipMemsetAsync(h->sig_done, 0, sizeof(uint64_t), h->stream));
-    }
-  }
-  if (const char* e = getenv("RCGP_HEAVY_RESERVE")) h->heavy_reserve_mod = atoi(e);
-  if (h->heavy_mode) {
-    int can = 0;
-    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess || !can ||
-        hipExtMallocWithFlags((void**)&h->sig_flag, sizeof(uint64_t), hipMallocSignalMemory) != hipSuccess) {
-      (void)hipGetLastError();
-      h->sig_flag = nullptr;
-      h->heavy_mode = 0;                               // no stream wait-value on this device: window pieces + bulk kernels
-    } else {
-      RC_HIP(hipMemsetAsync(h->sig_flag, 0, sizeof(uint64_t), h->stream));
-    }
-  }
-  RC_HIP(hipMalloc(&h->heavy_ctr, (2 * RC_MAX_PANELS + 2) * sizeof(int)));       // heavy-update counters per panel + k_prep2r's arrival counter
-  RC_HIP(hipMemsetAsync(h->heavy_ctr, 0, (2 * RC_MAX_PANELS + 2) * sizeof(int), h->stream));
-  if (const char* e = getenv("RCGP_INV_EVERY")) {
-    const int x = atoi(e);
-    if (x >= 1) h->inv_every = x;
-  }
-  if (const char* e = getenv("RCGP_DEPTH")) {
-    const int x = atoi(e);
-    if (x >= 1 && x <= 64) h->chain_depth = x;
-  }
-  if (const char* e = getenv("RCGP_NB")) {
-    const int64_t nb = atoll(e);
-    if (nb >= 128 && nb <= 4096 && nb % 128 == 0) h->nb_outer = nb;
-  }
   RC_HIP(hipMalloc(&h->X, (size_t)Np * M * sizeof(double)));
   RC_HIP(hipMalloc(&h->Z, (size_t)Np * M * sizeof(double)));
   RC_HIP(hipMalloc(&h->sq, (size_t)Np * sizeof(double)));
@@ -473,10 +365,7 @@ static int ensure_factor(rcgp_handle_s* h, bool want_inverse) {
   if ((rc = need_hyper(h))) return rc;
   if (!h->factored) {
     if ((rc = do_gram(h))) return rc;
-    h->overlap_inverse = want_inverse && h->overlap_ok;
-    rc = rc_potrf(h);
-    h->overlap_inverse = false;
-    if (rc) return rc;
+    if ((rc = rc_potrf(h))) return rc;
   }
   if (want_inverse && !h->inverted) {
     if ((rc = rc_trtri(h))) return rc;
@@ -501,7 +390,6 @@ RC_API int rcgp_stage_potrf(rcgp_handle h) {
     h->err = "rcgp_stage_potrf: no fresh Gram matrix (call rcgp_stage_gram first; a factorisation consumes it)";
     return -5;
   }
-  h->tt_active = false;
   return rc_potrf(h);
 }
 

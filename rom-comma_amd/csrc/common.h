@@ -12,10 +12,8 @@
 #define RC_BK 16               // k-depth of one LDS stage of the MFMA GEMM
 #define RC_MAX_M 64            // largest input dimensionality supported by the fused kernels
 #define RC_MAX_L 16            // most outputs of one covariant GP
-#define RC_RESERVE_CUS_DEFAULT 0   // CUs the bulk-update stream leaves to the panel chain (RCGP_RESERVE_CUS); 0 = no CU mask
 #define RC_SCAL_ELEMS 256      // h->scal: [0,2) LML sums, [8, 8+M+2) gradient sums, [RC_SCAL_INFO] the Cholesky status word
 #define RC_SCAL_INFO 128
-#define RC_MAX_PANELS 512        // outer panels of one factorisation the heavy-update counters provide for
 #define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -36,59 +34,23 @@ struct RcProfEvent { hipEvent_t start, stop; int cls; };
 struct rcgp_handle_s {
   int device = 0;
   bool streams_acquired = false;     // this handle holds a reference on its device's shared stream set (api.hip)
-  std::tuple<int, int, int> streams_key;
-  hipStream_t stream = nullptr;      // main stream: every public call is ordered on it
-  hipStream_t stream2 = nullptr;     // high-priority side stream: the chain of diagonal kernels (+ k_prep_next) inside rc_potrf
-  hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky (with RCGP_RESERVE_CUS = n > 0: CU mask, n CUs left free)
-  hipStream_t stream4 = nullptr;     // L^-1 kernels overlapped with the chain-bound tail of the Cholesky (rejected mode; masked like stream3 when that is)
-  hipStream_t stream5 = nullptr;     // column work of the fine-grained panel chain (T2/G kernels, potrf.hip)
-  hipStream_t stream6 = nullptr;     // the far part of that column work (block columns the next chain step does not read)
-  int prep_split = 2;                // the chain's critical step: 3 = factor-only diagonal kernel + k_prep1s (substitution) + k_prep2, the 128x128 inverse
-                                     // off the critical path; 2 / 1 = k_prep1 (explicit inverse; 8 / 4 waves) + k_prep2; 0 = k_prep_next on one CU (RCGP_PSPLIT)
-  bool prep_attr_set = false, prep_s_attr_set = false, subst_attr_set = false;
-  int grad_order = 0;                // k_grad tile order: 0 = heavy-first rows; 1 = 8 x 8 super-blocks per XCD with a common k start (measured: HBM reads -7 %,
-                                     // time +13 % -- prefetching workgroups drift apart) (RCGP_GRAD_ORDER)
-  bool prep_small = false;           // the tile solve as 32 small workgroups (k_prep1q + k_prep2r) instead of 8 whole-CU ones (RCGP_PREP_SMALL)
-  int dloop = 0;                     // 1: the diagonal kernel is one resident workgroup for the whole factorisation (k_diag_loop) and the tile
-                                     // solve reads the inverse from global memory (k_prep1g: 17 KB of LDS) -- no whole-CU launch on the chain (RCGP_DLOOP)
-  bool dloop_attr_set = false, prepg_attr_set = false, prepq_attr_set = false;
-  uint64_t* sig_ready = nullptr;     // signal memory: block jb may be factored (raised by a stream op behind P(jb-1))
-  uint64_t* sig_done = nullptr;      // signal memory: blocks < value - base are factored and inverted
-  uint64_t dl_base = 0;              // base value of the current factorisation (grows by 2^20 per factorisation)
-  int heavy_mode = 0;                // 1: one persistent k_heavy_update per finished panel instead of window pieces + bulk kernel (RCGP_HEAVY)
-  int heavy_reserve_mod = 2;         // its workgroups stay off cu 4 of every heavy_reserve_mod-th shader engine (1: 32 CUs, 2: 16, 4: 8; 0: none) (RCGP_HEAVY_RESERVE)
-  uint64_t* sig_flag = nullptr;      // 8 bytes of signal memory: progress word of the heavy update (hipStreamWaitValue64)
-  uint64_t sig_value = 0;            // last value handed out (monotonic over the life of the handle)
-  int* heavy_ctr = nullptr;          // device: two counters per outer panel, zeroed at the start of every factorisation
-  bool pieces_on_bulk = false;       // window pieces on the bulk stream (RCGP_PIECES_ON_BULK)
-  int catchup_blocks = 0;            // block columns taller than this many blocks get ONE long-K catch-up update instead of a K=128 far update per step (RCGP_CATCHUP; 0 = off)
-  bool bulk_after_piece = false;     // a panel's bulk update waits for the panel's first window piece (RCGP_BULK_AFTER_PIECE)
-  bool t2_after_p = false;           // the panel solve waits for the chain's solved tile instead of the diagonal kernel (RCGP_T2WAIT)
-  bool short_k = true;               // K = 128 kernels of the panel chain request all their operand slabs up front (RCGP_SHORTK)
-  bool chain_split = true;           // near / far split of the chain's column update (RCGP_SPLIT)
-  hipEvent_t ev_inv = nullptr;       // last overlapped L^-1 kernel
-  bool overlap_ok = false;            // RCGP_OVERLAP_INVERSE=1 overlaps L^-1 with the Cholesky tail (measured SLOWER: long L^-1 tiles hold the
-                                      // CUs the panel chain needs: 109 vs 85 ms per evaluation at C2), so it is off
-  bool overlap_inverse = false;      // set by the caller of rc_potrf when L^-1 will be needed
-  int64_t tt_put_rows = 0;           // incremental L^-1 schedule: diagonal blocks copied so far
-  std::vector<int> tt_next_pair;     // per level: first pair not yet completed
-  std::vector<int> tt_T_rows;        // per level: C-part row tiles of that pair whose T phase is already issued
-  bool tt_active = false;
+  hipStream_t stream = nullptr;      // main stream: every public call is ordered on it (in rc_potrf: the window pieces)
+  hipStream_t stream2 = nullptr;     // high priority: the chain of diagonal kernels + the chain's tile inside rc_potrf
+  hipStream_t stream3 = nullptr;     // bulk trailing update of the look-ahead Cholesky
+  hipStream_t stream5 = nullptr;     // high priority: column work of the panel chain (panel solve, near update)
+  hipStream_t stream6 = nullptr;     // high priority: the far part of that column work (block columns the next chain step does not read)
+  bool prep_attr_set = false, subst_attr_set = false, diag_attr_set = false;   // dynamic-LDS attributes set on this device
   hipStream_t launch = nullptr;      // the stream kernels are currently launched on
   hipEvent_t launch_stop = nullptr;  // if set: the next RC_LAUNCH attaches this event to its dispatch (no separate marker packet)
   int prof_pending = -1;             // index of the profiling bracket whose events the next RC_LAUNCH carries
-  bool ext_events = true;            // chain events ride on the kernel dispatches instead of hipEventRecord (RCGP_EXTEV)
   std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing), handed out in order by next_event (potrf.hip)
   size_t la_cursor = 0;
-  bool lookahead = true;
-  bool fine_chain = true;            // split every chain step into a critical single-workgroup part and column work (RCGP_FINE)
-  int64_t nb_outer = RC_NB_OUTER;    // outer panel width (RCGP_NB)
-  int inv_every = 8;                 // with overlap_inverse: L^-1 kernels are fed every inv_every panels (RCGP_INV_EVERY)
-  int chain_depth = 2;               // column panels updated by their own kernels ahead of the bulk trailing update (RCGP_DEPTH >= 1)
-  int chain_ext = 4;                 // 128-blocks past its own panel that a chain step keeps up to date (RCGP_EXT >= 1)
-  bool diag_attr_set = false;
-  bool invdiag_full = true;          // invdiag holds the full 128x128 inverses (false after a substitution-based factorisation: only their 16x16 diagonal blocks)
-  int diag_variant = 2;              // 2 = MFMA 16-blocked kernel (k_diag2), 1 = register column sweep (k_diag)
+  // the five run-time knobs of the factorisation's schedule (environment, read once per process: api.hip)
+  bool lookahead = true;             // RCGP_LOOKAHEAD: 0 = strictly sequential potrf on the main stream
+  bool fine_chain = true;            // RCGP_FINE: 0 = one stream per panel chain (D, T, G in order), one-panel look-ahead
+  int64_t nb_outer = RC_NB_OUTER;    // RCGP_NB: outer panel width
+  int chain_depth = 2;               // RCGP_DEPTH >= 1: column panels updated by their own kernels ahead of the bulk trailing update
+  int chain_ext = 4;                 // RCGP_EXT >= 1: 128-blocks past its own panel that a chain step keeps up to date
   int64_t N = 0, Np = 0;       // training rows per output; rows of the whole system, L * Nb
   int64_t Nb = 0;              // N padded to a multiple of RC_TILE: rows of one output block (Nb == Np when L == 1)
   int L = 1;                   // outputs modelled jointly (covariant GP, rcgp_create_mo): system row a = l * Nb + n
@@ -112,7 +74,7 @@ struct rcgp_handle_s {
   double *A = nullptr;         // Np x Np: Gram, then L in the lower triangle
   double *Linv = nullptr;      // Np x Np: L^-1 (allocated on first use)
   double *S = nullptr;         // Np x Np scratch (trtri temporaries, predict) (allocated on first use)
-  double *invdiag = nullptr;   // (Np/128) x 128 x 128 inverses of the diagonal blocks of L
+  double *invdiag = nullptr;   // (Np/128) x 128 x 128: the eight 16x16 diagonal-block inverses of every diagonal block of L (in its diagonal 16-blocks)
   double *logdiag = nullptr;   // Np: log L_ii
   double *partial = nullptr;   // scratch for two-stage reductions
   size_t partial_elems = 0;
@@ -129,7 +91,6 @@ struct rcgp_handle_s {
   int64_t pred_cap = 0;        // rows of KsT / pmean / pvar
   int64_t pts_cap = 0;         // points Xs / Zs / sqs hold (>= pred_cap; predict_gradient grows it)
   double *gV = nullptr, *gC = nullptr;   // predict_gradient scratch
-  double *tile_tmp = nullptr;            // one dense 128 x 128 tile: the chain's solved tile between k_prep1q and k_prep2r
   int64_t g_rows = 0;
   int g_blocks = 0;                       // V^T V products gC has room for
   // sobol scratch
@@ -210,30 +171,15 @@ int rc_launch_cross_gram(rcgp_handle_s* h, int64_t n, int64_t np, int out = 0); 
 // ---- gemm.hip (all matrices row-major, dims multiples of 128)
 // C[i][j] -= sum_k P[i][k] P[j][k]   lower tiles of an n x n matrix, K = kk
 int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk);
-// the same as one persistent launch that stays off the reserved CUs and publishes the completion of its first n_first_cols columns
-int rc_launch_heavy_update(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk, int64_t n_first_cols,
-                           int* ctr, unsigned long long value);
 // C (m x n) -= Arows (m x kk) * Brows (n x kk)^T ; tiles strictly above the diagonal of C (given the global row/col offsets) skipped
 int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0);
-// panel trsm: P (m x 128) <- P * invL^T ; rhs (m) -= P_new * wj (128)
-int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double* invL, int64_t m, double* rhs, const double* wj);
-// critical step of the fine-grained chain, one workgroup: T (128 x 128, below the diagonal block) <- T * invL^T,
-// rhs (128) -= T_new * wj, then D (the next diagonal block) -= T_new * T_new^T
-int rc_launch_prep_next(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
-// the same in two kernels on 8 + 10 compute units (k_prep1 solves the tile, k_prep2 updates the diagonal block)
-int rc_launch_prep_split(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
-// the same with the tile solved by blocked forward substitution against L_jj itself (k_prep1s: needs only the 16x16 diagonal-block
-// inverses, which the factor-only diagonal kernel leaves in invL); the right-hand side is not touched
-int rc_launch_prep_subst(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL);
-// k_prep1g (the inverse read straight from global memory into MFMA fragments: 17 KB of LDS, fits any free slot) + k_prep2
-// substitution-based panel solve (k_trsm_subst) for m rows, and the chain's tile with the next diagonal block's update fused
+// panel solve by blocked substitution: P (m x 128) <- P * L_jj^-T (L_jj at Ljj with row stride ldp, its 16x16 diagonal-block inverses in the
+// diagonal blocks of invL), rhs (m) -= P_new * wj (128)
 int rc_launch_trsm_subst(rcgp_handle_s* h, double* P, int64_t ldp, const double* Ljj, const double* invL, int64_t m, double* rhs, const double* wj);
+// critical step of the fine-grained chain: the tile T (128 x 128, right below L_jj) solved the same way on eight CUs, rhs (128) -= T_new * wj,
+// then D (the next diagonal block) -= T_new * T_new^T
 int rc_launch_chain_tile(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL, double* rhs, const double* wj);
-int rc_launch_prep_g(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj);
-// k_prep1q (32 small workgroups, 49.5 KB of LDS) + k_prep2r (diagonal-block update, rhs rows, optional `ready` signal of the resident diagonal workgroup)
-int rc_launch_prep_q(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj, int* ctr,
-                     unsigned long long* ready, unsigned long long value);
 // L^-1 by recursive doubling, level s: T = B * Ainv (lower-tri Ainv) for C-part row tiles [ti0, ti0+nti) of pairs
 // [pair0, pair0+npairs); X21 = -Cinv * T for whole pairs
 int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti0, int nti);
@@ -250,14 +196,11 @@ int rc_launch_vtv(rcgp_handle_s* h, int64_t rows_padded, const double* V, double
 
 // ---- potrf.hip
 int rc_potrf(rcgp_handle_s* h);                              // blocked Cholesky of A in place, w = L^-1 y, logdiag
-int rc_launch_diag_loop(rcgp_handle_s* h, unsigned long long base);   // the resident diagonal workgroup (k_diag_loop) on h->launch
-int rc_launch_diag(rcgp_handle_s* h, int64_t j, int mode = 0);
-int rc_launch_inv128_batched(rcgp_handle_s* h);                  // every 128x128 inverse of the factor's diagonal blocks, one launch on h->launch   // diagonal block at row/col offset j: 0 = factor + invert + w_j, 1 = factor only, 2 = invert + w_j
+int rc_launch_diag(rcgp_handle_s* h, int64_t j);             // diagonal block at row/col offset j: factor, log L_ii, 16x16 diagonal-block inverses, w_j
+int rc_launch_inv128_batched(rcgp_handle_s* h);              // every 128x128 inverse of the factor's diagonal blocks into the diagonal of Linv, one launch
 
 // ---- solve.hip
-int rc_trtri_begin(rcgp_handle_s* h);                        // allocate Linv/S, reset the incremental schedule
-int rc_trtri_advance(rcgp_handle_s* h, int64_t done_rows);   // launch (on h->launch) every L^-1 kernel whose inputs are rows < done_rows of L
-int rc_trtri(rcgp_handle_s* h);                              // Linv = L^-1 (whatever the incremental schedule has not issued yet)
+int rc_trtri(rcgp_handle_s* h);                              // Linv = L^-1 (allocates Linv / S on first use)
 int rc_alpha(rcgp_handle_s* h);                              // alpha = Linv^T w
 int rc_lml_value(rcgp_handle_s* h, double* lml);             // from logdiag and w
 int rc_sobol_weight_sum(rcgp_handle_s* h, const double* phi, double pre, const double* alpha_host, double* sum);

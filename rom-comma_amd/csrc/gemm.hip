@@ -308,90 +308,6 @@ int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_heavy_update: the WHOLE K = NB trailing update of one finished outer panel (what the window pieces and the bulk k_syrk_lower do
-// between them) as ONE persistent launch that leaves room for the panel chain. A kernel trace of the C2 factorisation shows why:
-// with a window piece and a bulk kernel in flight every CU holds two long-running GEMM workgroups at all times, and the chain's
-// whole-CU kernels (k_diag2: 150 KB of LDS, k_prep1: 138 KB x 8) wait MILLISECONDS for a CU on which both slots happen to be free
-// together (k_prep1 2.5 ms instead of 7 us at the start of panel 2): bulk update and chain run one after the other, not side by side.
-//   * 256 workgroups, ONE per CU (84 KB of LDS: two do not fit a CU, one fits beside a 74 KB column-work workgroup), looping over the
-//     lower tiles of the trailing matrix through an atomic counter; tiles in column-major order, so the next panel's columns come first;
-//   * workgroups that find themselves on a RESERVED CU (HW_ID.cu_id == 4 on every reserve_mod-th shader engine: one CU per SE, up to
-//     32) return at once: the kernel never occupies those CUs, the chain's whole-CU kernels find them (HIP has no CU affinity for
-//     kernels; CU-masked queues put this runtime in a slower regime);
-//   * when the first n_first tiles (the first column panel = what the window piece did) are complete, the last finisher publishes
-//     `value` in `flag` (signal memory): the chain's streams wait for it with hipStreamWaitValue64 (3 us hand-over) -- a kernel
-//     boundary would only come at the end of the whole update.
-// No workgroup ever waits for another: nothing can deadlock. ctr[0] hands out tiles, ctr[1] counts finished first-panel tiles.
-// ---------------------------------------------------------------------------------------------------------------------
-#define RC_HEAVY_LDS_PAD 1284           // doubles on top of the operand ring: 84 000 B per workgroup
-
-__device__ __forceinline__ bool rc_on_reserved_cu(int reserve_mod) {
-  if (reserve_mod <= 0) return false;
-  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);       // HW_ID
-  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;  // XCC_ID
-  const int cu = (hw >> 8) & 15, se = (hw >> 13) & 7;
-  return cu == 4 && ((int)(xcc * 4 + se) % reserve_mod) == 0;
-}
-
-template <int WN>
-__global__ void RC_BOUNDS(WN) k_heavy_update(double* __restrict__ C, int64_t ldc, const double* __restrict__ P, int64_t ldp, int kk,
-                                                          int T, int ntiles, int n_first, int* __restrict__ ctr,
-                                                          unsigned long long* __restrict__ flag, unsigned long long value, int reserve_mod) {
-  // (the padding that keeps a second workgroup of this kernel off the CU is DYNAMIC shared memory, requested at launch: with it in the
-  // static size the compiler sees an LDS-bound occupancy of 2 waves per SIMD and spends 169 registers, which would keep the
-  // column-work workgroup off the CU as well)
-  __shared__ double lds[GEMM_LDS];
-  __shared__ int s_tile;
-  if (rc_on_reserved_cu(reserve_mod)) return;
-  for (;;) {
-    if (threadIdx.x == 0) s_tile = atomicAdd(&ctr[0], 1);
-    __syncthreads();
-    const int id = __builtin_amdgcn_readfirstlane(s_tile);      // workgroup-uniform: scalar registers, not 64 copies
-    if (id >= ntiles) break;
-    // column-major lower triangle: column tj holds the T - tj tiles ti = tj .. T-1; cum(tj) = tj T - tj (tj - 1) / 2
-    const double b = 2.0 * T + 1.0;
-    int tj = (int)((b - sqrt(b * b - 8.0 * (double)id)) * 0.5);
-    if (tj < 0) tj = 0;
-    if (tj > T - 1) tj = T - 1;
-    while (tj > 0 && (int64_t)tj * T - (int64_t)tj * (tj - 1) / 2 > id) --tj;
-    while ((int64_t)(tj + 1) * T - (int64_t)(tj + 1) * tj / 2 <= id) ++tj;
-    tj = __builtin_amdgcn_readfirstlane(tj);
-    const int ti = tj + (int)(id - ((int64_t)tj * T - (int64_t)tj * (tj - 1) / 2));
-    v4d acc[4][Geo<WN>::NI];
-    double* Ct = C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128;
-    acc_load_staged<WN>(acc, Ct, ldc, lds);
-    gemm_mainloop<true, true, WN, true>(P, ldp, (int64_t)ti * 128, P, ldp, (int64_t)tj * 128, 0, kk, acc, lds);
-    acc_store_staged<WN>(acc, Ct, ldc, lds);
-    if (id < n_first) {                              // a tile the chain is waiting for: publish it before it is counted
-      __threadfence();
-      __syncthreads();
-      if (threadIdx.x == 0 && atomicAdd(&ctr[1], 1) == n_first - 1) {
-        __threadfence();
-        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-    __syncthreads();                                 // s_tile is rewritten at the top
-  }
-}
-
-// K = kk update of the lower tiles of the n x n matrix at C with the panel P (n x kk), n_first_cols = columns (a multiple of 128) whose
-// completion is published in h->sig_flag as `value`; ctr = two zeroed ints.
-int rc_launch_heavy_update(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk, int64_t n_first_cols,
-                           int* ctr, unsigned long long value) {
-  const int T = (int)(n / 128);
-  if (T <= 0) return 0;
-  const int ntiles = (int)((int64_t)T * (T + 1) / 2);
-  const int cf = (int)std::min<int64_t>(n_first_cols / 128, T);
-  const int n_first = (int)((int64_t)cf * T - (int64_t)cf * (cf - 1) / 2);
-  RcProfScope ps(h, RC_K_GEMM, (double)n * (double)(n + 128) * (double)kk, true);
-  const int grid = ntiles < 256 ? ntiles : 256;
-  RC_LAUNCH((k_heavy_update<RC_WN>), dim3((unsigned)grid), dim3(128 * RC_WN), RC_HEAVY_LDS_PAD * sizeof(double), C, ldc, P, ldp, (int)kk, T, ntiles, n_first, ctr,
-            (unsigned long long*)h->sig_flag, value, h->heavy_reserve_mod);
-  RC_HIP(hipGetLastError());
-  return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // C (m x n) -= A (m x kk) * B (n x kk)^T, skipping tiles strictly above the global diagonal.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int WN, int STAGED>
@@ -431,7 +347,7 @@ int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double
   // the up-front-prefetch variant runs one workgroup per CU: it wins while the launch is one round of tiles (latency-bound: near / far
   // updates of the chain at N <= ~8000 and in the tail of larger systems: 46 -> 28 us per kernel) and loses when tiles queue for CUs
   // (N = 28672 factorisation 138.5 -> 140.9 ms with it everywhere)
-  if (kk == 128 && h->short_k && (m / 128) * (n / 128) <= 512 && m <= 96 * 128) {
+  if (kk == 128 && (m / 128) * (n / 128) <= 512 && m <= 96 * 128) {
     RC_LAUNCH((k_gemm_nt_sub_k128<RC_WN>), grid, block, 0, C, ldc, A, lda, B, ldb, row0, col0);
   } else {
     RC_LAUNCH((k_gemm_nt_sub<RC_WN, 3>), grid, block, 0, C, ldc, A, lda, B, ldb, (int)kk, row0, col0);
@@ -441,179 +357,11 @@ int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Panel triangular solve as a GEMM with the explicit inverse of the diagonal block: P <- P * invL^T (in place), and the
-// fused forward substitution of the right-hand side: rhs[rows] -= P_new * wj.
-// ---------------------------------------------------------------------------------------------------------------------
-// One 128-row tile of the panel solve: Pt (128 x 128) <- Pt * invL^T in place, rhs_t (128) -= Pt_new * wj.
-template <int WN, bool PRE = false>
-__device__ __forceinline__ void trsm_tile(double* Pt, int64_t ldp, const double* __restrict__ invL, double* rhs_t,
-                                          const double* __restrict__ wj, double* lds, double (*rowsum)[128]) {
-  v4d acc[4][Geo<WN>::NI];
-  acc_zero(acc);
-  if (PRE) {
-    RegsN<WN> ra[RC_PF], rb[RC_PF];
-    gemm_mainloop_pre<true, true, WN, false, 8, RC_PF>(Pt, ldp, 0, invL, 128, 0, 0, acc, lds, ra, rb, false);
-  } else {
-    gemm_mainloop<true, true, WN>(Pt, ldp, 0, invL, 128, 0, 0, 128, acc, lds);
-  }
-  RC_LANE_VARS(WN)
-  double wv[NI_];
-#pragma unroll
-  for (int ni = 0; ni < NI_; ++ni) wv[ni] = wj[wc_ + 16 * ni + fr_];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = wr_ + 16 * mi + 4 * r + fq_;
-      double s = 0.0;
-#pragma unroll
-      for (int ni = 0; ni < NI_; ++ni) {
-        const double v = acc[mi][ni][r];
-        Pt[(int64_t)row * ldp + wc_ + 16 * ni + fr_] = v;
-        s += v * wv[ni];
-      }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      s += __shfl_xor(s, 8);
-      if (fr_ == 0) rowsum[wave_ % WN][row] = s;            // one slot per column-wave: summed in a fixed order below
-    }
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    double s = 0.0;
-#pragma unroll
-    for (int c = 0; c < WN; ++c) s += rowsum[c][threadIdx.x];
-    rhs_t[threadIdx.x] -= s;
-  }
-}
-
-template <int WN>
-__global__ void RC_BOUNDS(WN) k_trsm_panel(double* __restrict__ P, int64_t ldp, const double* __restrict__ invL, double* __restrict__ rhs,
-                                           const double* __restrict__ wj) {
-  __shared__ double lds[GEMM_LDS];
-  __shared__ double rowsum[WN][128];
-  const int ti = blockIdx.x;
-  trsm_tile<WN>(P + (int64_t)ti * 128 * ldp, ldp, invL, rhs + (int64_t)ti * 128, wj, lds, rowsum);
-}
-
-template <int WN>
-__global__ void __launch_bounds__(128 * WN) k_trsm_panel_pre(double* __restrict__ P, int64_t ldp, const double* __restrict__ invL,
-                                                            double* __restrict__ rhs, const double* __restrict__ wj) {
-  __shared__ double lds[GEMM_LDS];
-  __shared__ double rowsum[WN][128];
-  const int ti = blockIdx.x;
-  trsm_tile<WN, true>(P + (int64_t)ti * 128 * ldp, ldp, invL, rhs + (int64_t)ti * 128, wj, lds, rowsum);
-}
-
-// Critical step of the fine-grained panel chain (potrf.hip), ONE workgroup: the tile T right below the diagonal block that has
-// just been factored becomes L_{j+1,j} = T * inv(L_jj)^T (rhs rows updated as in the panel solve), and the next diagonal
-// block receives its last update D -= L_{j+1,j} L_{j+1,j}^T, so the next diagonal kernel can start while the rest of the
-// column is still being solved on another stream. The second product reads the tile this workgroup has just written:
-// __syncthreads() orders global memory at workgroup scope, and one workgroup runs on one CU (one L1).
-template <int WN>
-__global__ void __launch_bounds__(128 * WN) k_prep_next(double* T, double* D, int64_t ld, const double* __restrict__ invL, double* rhs,
-                                          const double* __restrict__ wj) {
-  __shared__ double lds[GEMM_LDS];
-  __shared__ double rowsum[WN][128];
-  trsm_tile<WN>(T, ld, invL, rhs, wj, lds, rowsum);
-  __syncthreads();
-  v4d acc[4][Geo<WN>::NI];
-  acc_load<WN>(acc, D, ld);
-  gemm_mainloop<true, true, WN, true>(T, ld, 0, T, ld, 0, 0, 128, acc, lds);
-  acc_store<WN>(acc, D, ld);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same critical step on SEVERAL compute units (one workgroup cannot issue fp64 MFMAs faster than ~1 per 110 cycles and
-// SIMD): k_prep1 solves the tile in eight 16-row strips (one workgroup each, the triangular inverse in LDS, only the k <= j
-// part of every product), k_prep2 updates the lower 32x32 blocks of the next diagonal block from the solved tile.
-// Operands sit in LDS with an odd row stride (LP): the 16 lanes of a fragment read are 16 rows of one k.
+// k_prep2: the chain's last update of the NEXT diagonal block, D -= T T^T from the solved tile T (128 x 128) right below the block just
+// factored: ten workgroups, one lower 32x32 block of D each (four waves: its 16x16 tiles), operands in LDS with an odd row stride (LP:
+// the 16 lanes of a fragment read are 16 rows of one k), every global load in flight before the first wait.
 // ---------------------------------------------------------------------------------------------------------------------
 #define LP 129
-// NW = 4: column tiles w and 7 - w per wave (9 k-blocks each); NW = 8: tile w per wave, twice the loads in flight.
-template <int NW>
-__global__ void __launch_bounds__(64 * NW) k_prep1(double* T, int64_t ld, const double* __restrict__ invL, double* rhs,
-                                                   const double* __restrict__ wj) {
-  extern __shared__ double sm1[];                  // Inv[128][LP], Ts[16][LP], wv[128], red[NW][16]
-  double* Inv = sm1;
-  double* Ts = Inv + 128 * LP;
-  double* wv = Ts + 16 * LP;
-  double* red = wv + 128;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
-  const int r0 = 16 * blockIdx.x;
-  // Every global load of the kernel is issued before the first one is waited for: left as a loop the compiler emits load - wait -
-  // LDS store per iteration, i.e. 16-32 memory round trips in a row, and under the bulk update's traffic one round trip takes
-  // microseconds (this kernel went from 10 to 30-280 us beside a window piece).
-  constexpr int NLI = 128 * 64 / (64 * NW), NLT = (16 * 64 + 64 * NW - 1) / (64 * NW);
-  double2 vi[NLI], vt[NLT];
-#pragma unroll
-  for (int q = 0; q < NLI; ++q) {
-    const int e = t + 64 * NW * q, i = e >> 6, j2 = (e & 63) * 2;
-    vi[q] = make_double2(0.0, 0.0);
-    if (j2 <= i) vi[q] = *reinterpret_cast<const double2*>(invL + i * 128 + j2);
-  }
-#pragma unroll
-  for (int q = 0; q < NLT; ++q) {
-    const int e = t + 64 * NW * q, i = e >> 6, j2 = (e & 63) * 2;
-    vt[q] = make_double2(0.0, 0.0);
-    if (e < 16 * 64) vt[q] = *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2);
-  }
-  const double wreg = (t < 128) ? wj[t] : 0.0;
-#pragma unroll
-  for (int q = 0; q < NLI; ++q) {
-    const int e = t + 64 * NW * q, i = e >> 6, j2 = (e & 63) * 2;
-    Inv[i * LP + j2] = vi[q].x;
-    Inv[i * LP + j2 + 1] = vi[q].y;
-  }
-#pragma unroll
-  for (int q = 0; q < NLT; ++q) {
-    const int e = t + 64 * NW * q, i = e >> 6, j2 = (e & 63) * 2;
-    if (e < 16 * 64) {
-      Ts[i * LP + j2] = vt[q].x;
-      Ts[i * LP + j2 + 1] = vt[q].y;
-    }
-  }
-  if (t < 128) wv[t] = wreg;
-  __syncthreads();
-  double part[4] = {0.0, 0.0, 0.0, 0.0};           // this wave's share of (strip row fq + 4q) . wj
-#pragma unroll
-  for (int n = 0; n < 8 / NW; ++n) {
-    const int jt = (n == 0) ? wave : 7 - wave;
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    for (int kt = 0; kt <= jt; ++kt) {
-      double av[4], bv[4];
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        av[s2] = Ts[fr * LP + 16 * kt + 4 * s2 + fq];
-        bv[s2] = Inv[(16 * jt + fr) * LP + 16 * kt + 4 * s2 + fq];
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
-    }
-    const double w = wv[16 * jt + fr];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      T[(int64_t)(r0 + fq + 4 * q) * ld + 16 * jt + fr] = acc[q];
-      part[q] = __builtin_fma(acc[q], w, part[q]);
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    double v = part[q];
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    if (fr == 0) red[wave * 16 + fq + 4 * q] = v;
-  }
-  __syncthreads();
-  if (t < 16) {
-    double v = (red[t] + red[16 + t]) + (red[32 + t] + red[48 + t]);
-    if (NW == 8) v += (red[64 + t] + red[80 + t]) + (red[96 + t] + red[112 + t]);
-    rhs[r0 + t] -= v;
-  }
-}
-
 __global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, double* D, int64_t ld) {
   extern __shared__ double sm2[];                  // La[32][LP], Lb[32][LP]
   double* La = sm2;
@@ -622,7 +370,7 @@ __global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, do
   int bi = 0, rem = blockIdx.x;                     // lower 32x32 blocks of the 4x4 block grid, row by row
   while (rem > bi) { rem -= bi + 1; ++bi; }
   const int bj = rem;
-  double2 va[8], vb[8];                             // all 16 loads in flight together (see k_prep1)
+  double2 va[8], vb[8];                             // all 16 loads in flight together
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
@@ -664,83 +412,12 @@ __global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, do
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_prep1s: the tile below a freshly factored diagonal block solved WITHOUT the 128x128 inverse, by blocked forward substitution
-// against L_jj itself -- so that the chain's next step does not wait for the inversion (15 us of the diagonal kernel, now a kernel
-// of its own off the critical path). One workgroup per 16-row strip of the tile; with Y = X^T (128 x 16) the system is
-// L_jj Y = T^T, block by block  Y_c = inv(L_cc) (T^T_c - sum_{k<c} L_ck Y_k),  inv(L_cc) the 16x16 inverses the factor-only kernel
-// left in the diagonal blocks of invL. The whole recurrence stays in the registers of ONE wave: the C/D layout of a 16x16 MFMA
-// result (lane (j, q), register r: row q + 4 r, column j) IS the B-operand layout of the next four k-steps (k = 4 s + q: s = r), so
-// Y_k feeds the later products as it is, and T^T_c - ... goes into inv(L_cc) (...) the same way. 176 dependent MFMAs ~ 3 us.
-// The other waves only help to bring L_jj into LDS (all loads in flight before the first wait, as in k_prep1).
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_prep1s(double* T, int64_t ld, const double* __restrict__ Ljj, const double* __restrict__ invL) {
-  extern __shared__ double sm1s[];                 // Ls[128][LP]: strictly lower 16-blocks of L_jj, inv(L_cc) in the diagonal blocks; Ts[16][LP]
-  double* Ls = sm1s;
-  double* Ts = Ls + 128 * LP;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
-  const int r0 = 16 * blockIdx.x;
-  constexpr int NLI = 128 * 64 / 256, NLT = 16 * 64 / 256;
-  double2 vi[NLI], vt[NLT];
-#pragma unroll
-  for (int q = 0; q < NLI; ++q) {
-    const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
-    vi[q] = make_double2(0.0, 0.0);
-    if (j2 <= i) vi[q] = ((i >> 4) == (j2 >> 4)) ? *reinterpret_cast<const double2*>(invL + i * 128 + j2)
-                                                 : *reinterpret_cast<const double2*>(Ljj + (int64_t)i * ld + j2);
-  }
-#pragma unroll
-  for (int q = 0; q < NLT; ++q) {
-    const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
-    vt[q] = *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2);
-  }
-#pragma unroll
-  for (int q = 0; q < NLI; ++q) {
-    const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
-    // (a pair never straddles two 16-blocks: j2 is even; the diagonal-block inverses are lower triangular with zeros above)
-    Ls[i * LP + j2] = vi[q].x;
-    Ls[i * LP + j2 + 1] = (j2 + 1 <= i) ? vi[q].y : 0.0;
-  }
-#pragma unroll
-  for (int q = 0; q < NLT; ++q) {
-    const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
-    Ts[i * LP + j2] = vt[q].x;
-    Ts[i * LP + j2 + 1] = vt[q].y;
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  v4d Y[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    v4d acc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = Ts[fr * LP + 16 * c + fq + 4 * r];          // (T^T)_c in the C layout: row fq + 4r, column fr
-#pragma unroll
-    for (int k = 0; k < c; ++k) {
-      double av[4];
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) av[s2] = Ls[(16 * c + fr) * LP + 16 * k + 4 * s2 + fq];    // L_ck[i = fr][4 s + fq], negated by the MFMA
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Y[k][s2], acc, 0, 0, 1);
-    }
-    double xv[4];
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) xv[s2] = Ls[(16 * c + fr) * LP + 16 * c + 4 * s2 + fq];        // inv(L_cc)[i = fr][4 s + fq]
-    v4d y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) y = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[s2], acc[s2], y, 0, 0, 0);
-    Y[c] = y;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) T[(int64_t)(r0 + fr) * ld + 16 * c + fq + 4 * r] = y[r];        // X[fr][16 c + fq + 4 r] = Y_c[fq + 4 r][fr]
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // k_trsm_subst: a 128-row tile of the panel solve  X L_jj^T = T  by blocked forward substitution against L_jj ITSELF -- no 128x128
 // inverse anywhere on the factorisation's critical path (the diagonal kernel then only factors: 11 us less per chain step). What
 // it needs of L_jj are its 28 strictly-lower 16x16 blocks and the inverses of its 8 diagonal blocks (which the factor-only diagonal
 // kernel leaves in the diagonal blocks of invL); they are packed block by block into 77 KB of LDS (PB doubles per block, odd row
 // stride), so two workgroups share a CU.
-// One wave per 16-row strip, the whole recurrence in registers, as in k_prep1s: with Y = X^T the C/D layout of a 16x16
+// One wave per 16-row strip, the whole recurrence in registers, with Y = X^T the C/D layout of a 16x16
 // MFMA result (lane (fr, fq), register r: row fq + 4r, column fr) is the B-operand layout of the next products (k = 4s + fq, s = r):
 //     Y_c = inv(L_cc) (T^T_c - sum_{k<c} L_ck Y_k),  c = 0..7:   4c + 4 MFMAs, 144 per strip, the same count as the product with the
 // explicit triangular inverse; sequential along c, but an fp64 MFMA occupies the pipe for its whole 64-cycle latency anyway.
@@ -850,9 +527,9 @@ int rc_launch_chain_tile(rcgp_handle_s* h, double* T, double* D, int64_t ld, con
     RC_HIP(hipFuncSetAttribute((const void*)k_trsm_subst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_SUBST_LDS));
     h->subst_attr_set = true;
   }
-  if (!h->prep_s_attr_set) {
+  if (!h->prep_attr_set) {
     RC_HIP(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    h->prep_s_attr_set = true;
+    h->prep_attr_set = true;
   }
   {
     RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
@@ -864,318 +541,6 @@ int rc_launch_chain_tile(rcgp_handle_s* h, double* T, double* D, int64_t ld, con
     RC_LAUNCH(k_prep2, dim3(10), dim3(256), lds2, (const double*)T, D, ld);
     RC_HIP(hipGetLastError());
   }
-  return 0;
-}
-
-// k_prep1 with the inverse of L_jj read straight from global memory (L2) into the MFMA B fragments instead of through LDS: 17 KB of LDS
-// and 512 threads, so the workgroup fits into ANY free slot of a CU next to a resident GEMM workgroup -- k_prep1's 138 KB need a CU
-// with both slots free at once, for which it waited milliseconds at C2 (kernel trace). One 16-row strip of the tile per workgroup,
-// wave w the column tile w (k-blocks 0..w of the triangular inverse); every global load issued before the first wait.
-__global__ void __launch_bounds__(512) k_prep1g(double* T, int64_t ld, const double* __restrict__ invL, double* rhs, const double* __restrict__ wj) {
-  __shared__ double Ts[16 * LP];
-  __shared__ double red[8 * 16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
-  const int r0 = 16 * blockIdx.x, jt = wave;
-  double2 vt[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int e = t + 512 * q, i = e >> 6, j2 = (e & 63) * 2;
-    vt[q] = *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2);
-  }
-  double bv[8][4];
-#pragma unroll
-  for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) bv[kt][s2] = (kt <= jt) ? invL[(16 * jt + fr) * 128 + 16 * kt + 4 * s2 + fq] : 0.0;
-  const double w = wj[16 * jt + fr];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int e = t + 512 * q, i = e >> 6, j2 = (e & 63) * 2;
-    Ts[i * LP + j2] = vt[q].x;
-    Ts[i * LP + j2 + 1] = vt[q].y;
-  }
-  __syncthreads();
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int kt = 0; kt < 8; ++kt) {
-    if (kt <= jt) {
-      double av[4];
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) av[s2] = Ts[fr * LP + 16 * kt + 4 * s2 + fq];
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[kt][s2], acc, 0, 0, 0);
-    }
-  }
-  double part[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    T[(int64_t)(r0 + fq + 4 * q) * ld + 16 * jt + fr] = acc[q];
-    double v = acc[q] * w;
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    part[q] = v;
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if (fr == 0) red[wave * 16 + fq + 4 * q] = part[q];
-  __syncthreads();
-  if (t < 16) {
-    const double v = ((red[t] + red[16 + t]) + (red[32 + t] + red[48 + t])) + ((red[64 + t] + red[80 + t]) + (red[96 + t] + red[112 + t]));
-    rhs[r0 + t] -= v;
-  }
-}
-
-// k_prep1q: the chain's tile solve in 32 small workgroups (8 strips of 16 rows x 4 groups of two 16-column tiles), each staging only the
-// rows of the inverse its two column tiles need: 49.5 KB of LDS and 128 threads, so a workgroup fits into whatever is free beside a resident
-// GEMM workgroup -- and the loads stay coalesced row pieces, unlike k_prep1g's scattered fragment loads (49 us against 7). Wave w of group g
-// computes column tile 2 g + w. The solved tile goes to a dense scratch tile (the groups of a strip read each other's input columns, so nothing may
-// be written in place); k_prep2r reads it from there, copies it into the matrix and updates the right-hand side rows (a product over ALL columns).
-__global__ void __launch_bounds__(128) k_prep1q(const double* __restrict__ T, int64_t ld, const double* __restrict__ invL, double* __restrict__ Xout) {
-  extern __shared__ double smq[];                  // Ts[16][LP], Is[32][LP]
-  double* Ts = smq;
-  double* Is = Ts + 16 * LP;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
-  const int r0 = 16 * (blockIdx.x & 7), g = blockIdx.x >> 3;
-  const int c0 = 32 * g;                           // first column (= first row of the inverse) of this group
-  const int kmax = 32 * g + 32;                    // the triangular inverse: row c has entries k <= c only
-  double2 vt[8], vi[16];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int e = t + 128 * q, i = e >> 6, j2 = (e & 63) * 2;
-    vt[q] = (j2 < kmax) ? *reinterpret_cast<const double2*>(T + (int64_t)(r0 + i) * ld + j2) : make_double2(0.0, 0.0);
-  }
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int e = t + 128 * q, i = e >> 6, j2 = (e & 63) * 2;
-    vi[q] = (j2 <= c0 + i) ? *reinterpret_cast<const double2*>(invL + (c0 + i) * 128 + j2) : make_double2(0.0, 0.0);
-  }
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int e = t + 128 * q, i = e >> 6, j2 = (e & 63) * 2;
-    Ts[i * LP + j2] = vt[q].x;
-    Ts[i * LP + j2 + 1] = vt[q].y;
-  }
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int e = t + 128 * q, i = e >> 6, j2 = (e & 63) * 2;
-    Is[i * LP + j2] = vi[q].x;
-    Is[i * LP + j2 + 1] = (j2 + 1 <= c0 + i) ? vi[q].y : 0.0;
-  }
-  __syncthreads();
-  const int jt = 2 * g + wave;
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
-  for (int kt = 0; kt <= jt; ++kt) {
-    double av[4], bv[4];
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      av[s2] = Ts[fr * LP + 16 * kt + 4 * s2 + fq];
-      bv[s2] = Is[(16 * wave + fr) * LP + 16 * kt + 4 * s2 + fq];
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
-  }
-#pragma unroll
-  // OUT OF PLACE (dense 128 x 128 scratch): the other column groups of this strip are still reading the tile
-  for (int q = 0; q < 4; ++q) Xout[(r0 + fq + 4 * q) * 128 + 16 * jt + fr] = acc[q];
-}
-
-// k_prep2 plus (a) workgroup 10: the right-hand side rows of the block, rhs -= X w_j over all 128 columns of the solved tile (fixed order),
-// and (b) optionally the signal of the resident diagonal workgroup: the LAST of the 11 workgroups to finish raises `ready` to `value`
-// (counter ctr, reset for the next launch: launches of this kernel follow each other on one stream).
-__global__ void __launch_bounds__(256) k_prep2r(const double* __restrict__ Lt, double* __restrict__ Tdst, double* D, int64_t ld, double* rhs,
-                                                const double* __restrict__ wj, int* ctr, unsigned long long* ready, unsigned long long value) {
-  extern __shared__ double sm2[];                  // La[32][LP], Lb[32][LP]
-  const int t = threadIdx.x;
-  if (blockIdx.x == 10) {
-    const int i = t >> 1, half = t & 1;
-    const double* row = Lt + i * 128 + 64 * half;
-    double* dst = Tdst + (int64_t)i * ld + 64 * half;
-    const double* wv = wj + 64 * half;
-    double sacc = 0.0;
-#pragma unroll 1
-    for (int c = 0; c < 2; ++c) {                    // 16 sixteen-byte loads of the row in flight at a time
-      double2 xv[16], wv2[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        xv[q] = *reinterpret_cast<const double2*>(row + 32 * c + 2 * q);
-        wv2[q] = *reinterpret_cast<const double2*>(wv + 32 * c + 2 * q);
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        *reinterpret_cast<double2*>(dst + 32 * c + 2 * q) = xv[q];            // the solved tile into the matrix
-        sacc = __builtin_fma(xv[q].y, wv2[q].y, __builtin_fma(xv[q].x, wv2[q].x, sacc));
-      }
-    }
-    const double other = __shfl_xor(sacc, 1);
-    if (half == 0) rhs[i] -= (sacc + other);
-  } else {
-    double* La = sm2;
-    double* Lb = La + 32 * LP;
-    const int lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
-    int bi = 0, rem = blockIdx.x;
-    while (rem > bi) { rem -= bi + 1; ++bi; }
-    const int bj = rem;
-    double2 va[8], vb[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
-      va[q] = *reinterpret_cast<const double2*>(Lt + (32 * bi + i) * 128 + j2);
-      vb[q] = *reinterpret_cast<const double2*>(Lt + (32 * bj + i) * 128 + j2);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int e = t + 256 * q, i = e >> 6, j2 = (e & 63) * 2;
-      La[i * LP + j2] = va[q].x;
-      La[i * LP + j2 + 1] = va[q].y;
-      Lb[i * LP + j2] = vb[q].x;
-      Lb[i * LP + j2 + 1] = vb[q].y;
-    }
-    const int ti = wave >> 1, tj = wave & 1;
-    double* Dt = D + (int64_t)(32 * bi + 16 * ti) * ld + 32 * bj + 16 * tj;
-    const bool needed = !(bi == bj && tj > ti);
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    if (needed) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = Dt[(int64_t)(fq + 4 * q) * ld + fr];
-    }
-    __syncthreads();
-    if (needed) {
-#pragma unroll 2
-      for (int kt = 0; kt < 8; ++kt) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-          av[s2] = La[(16 * ti + fr) * LP + 16 * kt + 4 * s2 + fq];
-          bv[s2] = Lb[(16 * tj + fr) * LP + 16 * kt + 4 * s2 + fq];
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 1);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Dt[(int64_t)(fq + 4 * q) * ld + fr] = acc[q];
-    }
-  }
-  if (ready) {
-    __threadfence();
-    __syncthreads();
-    if (t == 0 && atomicAdd(ctr, 1) == (int)gridDim.x - 1) {
-      atomicExch(ctr, 0);
-      __threadfence();
-      __hip_atomic_store(ready, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-
-// tile solve in small workgroups + diagonal-block update + rhs rows (+ the resident diagonal workgroup's signal when ready != null)
-int rc_launch_prep_q(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj, int* ctr,
-                     unsigned long long* ready, unsigned long long value) {
-  const size_t lds1 = (size_t)(48 * LP) * sizeof(double), lds2 = (size_t)(64 * LP) * sizeof(double);
-  if (!h->prepq_attr_set) {
-    RC_HIP(hipFuncSetAttribute((const void*)k_prep1q, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    RC_HIP(hipFuncSetAttribute((const void*)k_prep2r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    h->prepq_attr_set = true;
-  }
-  if (!h->tile_tmp) RC_HIP(hipMalloc(&h->tile_tmp, 128 * 128 * sizeof(double)));
-  hipEvent_t ev = h->launch_stop;                    // "the tile is solved" is true only after k_prep2r has copied it into the matrix
-  h->launch_stop = nullptr;
-  {
-    RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
-    RC_LAUNCH(k_prep1q, dim3(32), dim3(128), lds1, (const double*)T, ld, invL, h->tile_tmp);
-    RC_HIP(hipGetLastError());
-  }
-  h->launch_stop = ev;
-  {
-    RcProfScope ps(h, RC_K_GEMM, 128.0 * 129.0 * 128.0, true);
-    RC_LAUNCH(k_prep2r, dim3(11), dim3(256), lds2, (const double*)h->tile_tmp, T, D, ld, rhs, wj, ctr, ready, value);
-    RC_HIP(hipGetLastError());
-  }
-  return 0;
-}
-
-int rc_launch_prep_g(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
-  const size_t lds2 = (size_t)(64 * LP) * sizeof(double);
-  if (!h->prepg_attr_set) {
-    RC_HIP(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    h->prepg_attr_set = true;
-  }
-  {
-    RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
-    RC_LAUNCH(k_prep1g, dim3(8), dim3(512), 0, T, ld, invL, rhs, wj);
-    RC_HIP(hipGetLastError());
-  }
-  {
-    RcProfScope ps(h, RC_K_GEMM, 128.0 * 129.0 * 128.0, true);
-    RC_LAUNCH(k_prep2, dim3(10), dim3(256), lds2, (const double*)T, D, ld);
-    RC_HIP(hipGetLastError());
-  }
-  return 0;
-}
-
-int rc_launch_prep_subst(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* Ljj, const double* invL) {
-  const size_t lds1 = (size_t)(128 * LP + 16 * LP) * sizeof(double), lds2 = (size_t)(64 * LP) * sizeof(double);
-  if (!h->prep_s_attr_set) {
-    RC_HIP(hipFuncSetAttribute((const void*)k_prep1s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    RC_HIP(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    h->prep_s_attr_set = true;
-  }
-  {
-    RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
-    RC_LAUNCH(k_prep1s, dim3(8), dim3(256), lds1, T, ld, Ljj, invL);
-    RC_HIP(hipGetLastError());
-  }
-  {
-    RcProfScope ps(h, RC_K_GEMM, 128.0 * 129.0 * 128.0, true);
-    RC_LAUNCH(k_prep2, dim3(10), dim3(256), lds2, (const double*)T, D, ld);
-    RC_HIP(hipGetLastError());
-  }
-  return 0;
-}
-
-// T solved and rhs rows updated (k_prep1, which carries a pending h->launch_stop: the column work only needs the solved tile),
-// then the next diagonal block updated (k_prep2).
-int rc_launch_prep_split(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
-  const size_t lds1 = (size_t)(128 * LP + 16 * LP + 128 + 128) * sizeof(double), lds2 = (size_t)(64 * LP) * sizeof(double);
-  if (!h->prep_attr_set) {
-    RC_HIP(hipFuncSetAttribute((const void*)k_prep1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    RC_HIP(hipFuncSetAttribute((const void*)k_prep1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    RC_HIP(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    h->prep_attr_set = true;
-  }
-  {
-    RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
-    if (h->prep_split == 2) {
-      RC_LAUNCH(k_prep1<8>, dim3(8), dim3(512), lds1, T, ld, invL, rhs, wj);
-    } else {
-      RC_LAUNCH(k_prep1<4>, dim3(8), dim3(256), lds1, T, ld, invL, rhs, wj);
-    }
-    RC_HIP(hipGetLastError());
-  }
-  {
-    RcProfScope ps(h, RC_K_GEMM, 128.0 * 129.0 * 128.0, true);
-    RC_LAUNCH(k_prep2, dim3(10), dim3(256), lds2, (const double*)T, D, ld);
-    RC_HIP(hipGetLastError());
-  }
-  return 0;
-}
-
-int rc_launch_prep_next(rcgp_handle_s* h, double* T, double* D, int64_t ld, const double* invL, double* rhs, const double* wj) {
-  RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0 + 128.0 * 129.0 * 128.0, true);
-  RC_LAUNCH(k_prep_next<RC_WN>, dim3(1), dim3(128 * RC_WN), 0, T, D, ld, invL, rhs, wj);
-  RC_HIP(hipGetLastError());
-  return 0;
-}
-
-int rc_launch_trsm_panel(rcgp_handle_s* h, double* P, int64_t ldp, const double* invL, int64_t m, double* rhs, const double* wj) {
-  if (m <= 0) return 0;
-  RcProfScope ps(h, RC_K_GEMM, (double)m * 128.0 * 128.0, true);     // triangular: m*128*128 flops algorithmic
-  if (h->short_k && m <= 96 * 128) {                       // (same rule as the K = 128 update: the latency-bound regime only)
-    RC_LAUNCH(k_trsm_panel_pre<RC_WN>, dim3((unsigned)(m / 128)), dim3(128 * RC_WN), 0, P, ldp, invL, rhs, wj);
-  } else {
-    RC_LAUNCH(k_trsm_panel<RC_WN>, dim3((unsigned)(m / 128)), dim3(128 * RC_WN), 0, P, ldp, invL, rhs, wj);
-  }
-  RC_HIP(hipGetLastError());
   return 0;
 }
 
@@ -1238,36 +603,18 @@ int rc_launch_trtri_X(rcgp_handle_s* h, int64_t s, int pair0, int npairs) {
 //   Wij = alpha_i alpha_j - Kinv_ij ; G_m = sum Wij Kij (z_im - z_jm)^2 ; G_var = sum Wij Kij ; G_noise = tr W
 // K^-1 is never written: each lower tile is reduced in the epilogue to M+2 partial sums (row blockIdx of h->partial).
 // ---------------------------------------------------------------------------------------------------------------------
-// Tile order (order = 1): 8 x 8 super-blocks of tiles, ONE PER XCD AT A TIME. Blocks are dealt round-robin over the 8 XCDs (block b and
-// b + 8 share one: MI355X_MICROARCH.md, workgroup dispatch -- a speed assumption only), so the 64 tiles of a super-block are given to
-// blocks with equal b % 8: the 64 workgroups resident on an XCD then stream 8 + 8 operand panels through that XCD's L2 instead of
-// 64 + 64, PROVIDED they walk k together -- so every tile of a super-block starts at the block's first k (I * 1024) instead of its
-// own ti * 128: the extra slabs multiply the zero upper triangle of L^-1 (zeroed once at allocation), add exactly +0 and cost <= 7/8
-// of a tile row per super-row (~5 % more slab iterations); all 64 tiles then have the same trip count and finish together.
-// Super-blocks go out heaviest first (I ascending = longest k-range), every 8th one to the same XCD. Results are bit-identical.
+// Tiles go out in row order of the lower triangle, heaviest k-ranges first by construction of tri_decode's enumeration (an 8 x 8
+// super-block order per XCD was measured: HBM reads -7 %, time +13 % -- DESIGN.md).
 template <int LZ, int WN>
 __global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld, int64_t Np, int64_t N, int M, const double* __restrict__ Z,
                                      const double* __restrict__ sq, const double* __restrict__ alpha, double var,
-                                     double* __restrict__ partial, int order, int nsb) {
+                                     double* __restrict__ partial) {
   constexpr int ZL = 2 * 128 * LZ;
   constexpr int NW = 2 * WN;                                  // waves per workgroup
   __shared__ double lds[(GEMM_LDS > ZL ? GEMM_LDS : ZL) + NW * (RC_MAX_M + 2)];
   int ti, tj;
-  int64_t kstart;
-  if (order == 0) {
-    tri_decode(blockIdx.x, ti, tj);
-    kstart = (int64_t)ti * 128;
-  } else {
-    const int b = blockIdx.x, g = b & 7, q = b >> 3;
-    const int sb = (q >> 6) * 8 + g, t64 = q & 63;
-    if (sb >= nsb) return;
-    int I, J;
-    tri_decode(sb, I, J);
-    ti = I * 8 + (t64 >> 3);
-    tj = J * 8 + (t64 & 7);
-    if ((int64_t)ti * 128 >= Np || tj > ti) return;
-    kstart = (int64_t)I * 1024;
-  }
+  tri_decode(blockIdx.x, ti, tj);
+  const int64_t kstart = (int64_t)ti * 128;
   const int64_t tile_id = (int64_t)ti * (ti + 1) / 2 + tj;     // row of `partial`
   v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
@@ -1357,16 +704,13 @@ int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
   if (rc) return rc;
   const double np = (double)h->Np;
   RcProfScope ps(h, RC_K_GRAD, np * np * np / 3.0);
-  const int64_t TS = (T + 7) / 8;                                 // super-rows of 8 tile rows
-  const int nsb = (int)(TS * (TS + 1) / 2);
-  const int order = h->grad_order;
-  const unsigned grid = order ? (unsigned)(((nsb + 7) / 8) * 8 * 64) : (unsigned)nb;
+  const unsigned grid = (unsigned)nb;
   if (h->M <= 32)
     hipLaunchKernelGGL((k_grad<33, RC_WN>), dim3(grid), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
-                       h->sq, h->alpha, h->var, h->partial, order, nsb);
+                       h->sq, h->alpha, h->var, h->partial);
   else
     hipLaunchKernelGGL((k_grad<65, RC_WN>), dim3(grid), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
-                       h->sq, h->alpha, h->var, h->partial, order, nsb);
+                       h->sq, h->alpha, h->var, h->partial);
   RC_HIP(hipGetLastError());
   *nrows = (int)nb;
   return 0;

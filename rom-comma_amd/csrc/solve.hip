@@ -12,92 +12,37 @@ int rc_ensure_partial(rcgp_handle_s* h, size_t elems) {
   return 0;
 }
 
-__global__ void k_put_diag(double* __restrict__ W, int64_t ld, const double* __restrict__ invdiag, int64_t b0) {
-  const int64_t b = b0 + blockIdx.x;
-  double* Wt = W + b * 128 * ld + b * 128;
-  const double* src = invdiag + b * 128 * 128;
-  for (int e = threadIdx.x; e < 128 * 128; e += blockDim.x) Wt[(int64_t)(e >> 7) * ld + (e & 127)] = src[e];
-}
-
-// Incremental triangular inverse. Level k has block size s = 128 << k; pair p of that level inverts rows [2ps, 2ps+2s) from the
-// inverses of its halves: A part [2ps, 2ps+s), C part [2ps+s, min(2ps+2s, Np)). A kernel may run as soon as the rows of L it
-// reads are final: the T phase of C-part row tile t needs L rows of that tile and the finished A^-1; the X phase needs the whole
-// pair. rc_trtri_advance(done_rows) issues, in level order on h->launch (one stream => in-order => dependencies hold),
-// everything that has become runnable; the Cholesky calls it after every panel, rc_trtri() finishes with done_rows = Np.
-int rc_trtri_begin(rcgp_handle_s* h) {
+// L^-1 by recursive doubling. Level 0: the 128x128 inverses of the diagonal blocks, all in one launch (k_inv128_batched, potrf.hip).
+// Level k has block size s = 128 << k; pair p of that level inverts rows [2ps, 2ps+2s) from the inverses of its halves -- A part
+// [2ps, 2ps+s), C part [2ps+s, min(2ps+2s, Np)): T = B A^-1 (k_trtri_T), X21 = -C^-1 T (k_trtri_X) -- every pair of a level in one
+// launch of each (the last pair may be short: a launch of its own). One stream, in order.
+int rc_trtri(rcgp_handle_s* h) {
   const int64_t Np = h->Np;
+  int rc;
   if (!h->Linv) {
     RC_HIP(hipMalloc(&h->Linv, (size_t)Np * Np * sizeof(double)));
-    // the strictly upper 128-blocks are never written afterwards: zero once, so that k_grad may run a tile's k-range from the start of
-    // its super-block (multiplying zeros) instead of from its own diagonal
+    // the strictly upper 128-blocks are never written afterwards: zero once (readers may then run a k-range from a block boundary)
     RC_HIP(hipMemsetAsync(h->Linv, 0, (size_t)Np * Np * sizeof(double), h->stream));
   }
   if (!h->S) RC_HIP(hipMalloc(&h->S, (size_t)Np * Np * sizeof(double)));
-  int levels = 0;
-  for (int64_t s = 128; s < Np; s *= 2) ++levels;
-  h->tt_next_pair.assign(levels, 0);
-  h->tt_T_rows.assign(levels, 0);
-  h->tt_put_rows = 0;
-  h->tt_active = true;
-  return 0;
-}
-
-int rc_trtri_advance(rcgp_handle_s* h, int64_t done_rows) {
-  const int64_t Np = h->Np;
-  int rc;
-  if (done_rows > Np) done_rows = Np;
-  if (done_rows > h->tt_put_rows) {
-    if (!h->invdiag_full && (rc = rc_launch_inv128_batched(h))) return rc;
-    RcProfScope ps(h, RC_K_MISC, 0.0);
-    hipLaunchKernelGGL(k_put_diag, dim3((unsigned)((done_rows - h->tt_put_rows) / 128)), dim3(256), 0, h->launch, h->Linv, Np, h->invdiag,
-                       h->tt_put_rows / 128);
-    RC_HIP(hipGetLastError());
-    h->tt_put_rows = done_rows;
-  }
-  int k = 0;
-  for (int64_t s = 128; s < Np; s *= 2, ++k) {
+  if ((rc = rc_launch_inv128_batched(h))) return rc;
+  for (int64_t s = 128; s < Np; s *= 2) {
     const int total_pairs = (int)((Np - s + 2 * s - 1) / (2 * s));            // pairs with a non-empty C part: 2ps + s < Np
-    while (h->tt_next_pair[k] < total_pairs) {
-      const int p = h->tt_next_pair[k];
+    int p = 0;
+    while (p < total_pairs) {
       const int64_t rowC = 2 * s * (int64_t)p + s, rowEnd = (rowC + s < Np) ? rowC + s : Np;
-      if (rowEnd <= done_rows) {
-        // complete pair(s): batch every consecutive complete pair that has no partial T work issued
-        int q = p;
-        if (h->tt_T_rows[k] == 0) {
-          while (q < total_pairs) {
-            const int64_t rc2 = 2 * s * (int64_t)q + s, re2 = (rc2 + s < Np) ? rc2 + s : Np;
-            if (re2 > done_rows || re2 - rc2 != rowEnd - rowC) break;          // same shape only (the last pair may be short)
-            ++q;
-          }
-          if ((rc = rc_launch_trtri_T(h, s, p, q - p, 0, (int)((rowEnd - rowC) / 128)))) return rc;
-        } else {
-          if ((rc = rc_launch_trtri_T(h, s, p, 1, h->tt_T_rows[k], (int)((rowEnd - rowC) / 128) - h->tt_T_rows[k]))) return rc;
-          q = p + 1;
-        }
-        if ((rc = rc_launch_trtri_X(h, s, p, q - p))) return rc;
-        h->tt_next_pair[k] = q;
-        h->tt_T_rows[k] = 0;
-      } else {
-        if (rowC < done_rows) {                                                // A part final: T phase of the C rows that are final
-          const int avail = (int)((done_rows - rowC) / 128);
-          if (avail > h->tt_T_rows[k]) {
-            if ((rc = rc_launch_trtri_T(h, s, p, 1, h->tt_T_rows[k], avail - h->tt_T_rows[k]))) return rc;
-            h->tt_T_rows[k] = avail;
-          }
-        }
-        break;
+      int q = p;
+      while (q < total_pairs) {                                               // consecutive pairs of the same shape
+        const int64_t rc2 = 2 * s * (int64_t)q + s, re2 = (rc2 + s < Np) ? rc2 + s : Np;
+        if (re2 - rc2 != rowEnd - rowC) break;
+        ++q;
       }
+      if ((rc = rc_launch_trtri_T(h, s, p, q - p, 0, (int)((rowEnd - rowC) / 128)))) return rc;
+      if ((rc = rc_launch_trtri_X(h, s, p, q - p))) return rc;
+      p = q;
     }
   }
   return 0;
-}
-
-int rc_trtri(rcgp_handle_s* h) {
-  int rc;
-  if (!h->tt_active && (rc = rc_trtri_begin(h))) return rc;
-  rc = rc_trtri_advance(h, h->Np);
-  h->tt_active = false;
-  return rc;
 }
 
 // partial[kc][j] = sum_{k in chunk kc, k >= tile start of j} Linv[k][j] * w[k]   (rows above the diagonal tile are never read)

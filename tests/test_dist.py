@@ -138,3 +138,97 @@ def test_failure_agreement_without_a_process_group():
     dist.agree_on_failure(None)
     with pytest.raises(KeyError):
         dist.agree_on_failure(KeyError('x'))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Eight ranks over gloo on the CPU: the host logic of the one-output-per-GPU configuration (BASELINE configs[3]) and
+# of bench.py's N > 1 path with the device calls answered by the oracle (tests/oracle_backend.py -- test infrastructure; the product has
+# no CPU path). What runs for real: Y_splits_sharded, the per-rank folds and fits, OutputShard's two all-gathers, gsa_outputs' per-fold
+# agreement, rank 0's csv stores and Collect; bench.py's fold schedule, gather table and value formula.
+# --------------------------------------------------------------------------------------------------------------------
+
+def _eight_output_repo(folder: Path, N=44, M=3, L=8, seed=0):
+    import pandas as pd
+    from romcomma_amd.data.storage import Repository
+    rng = np.random.default_rng(seed)
+    U = rng.random((N, M))
+    Y = np.stack([np.sin(2 * np.pi * U[:, l % M]) + 0.4 * (l + 1) / L * U[:, (l + 1) % M] ** 2 + 0.2 * U[:, (l + 2) % M] for l in range(L)], axis=1)
+    Y += 0.03 * rng.standard_normal((N, L))
+    columns = pd.MultiIndex.from_tuples([('X', f'X.{m}') for m in range(M)] + [('Y', f'Y.{l}') for l in range(L)])
+    return Repository.from_df(folder, pd.DataFrame(np.concatenate([U, Y], axis=1), columns=columns))
+
+
+def _outputs_worker(rank: int, world: int, port: int, repo_folder: str, drop_model_of_rank: int):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import oracle_backend
+    oracle_backend.install()
+    import shutil
+    from romcomma_amd import dist
+    from romcomma_amd.data.storage import Repository
+    from romcomma_amd.user import run
+    dist.init_process_group('gloo')
+    repo = Repository(Path(repo_folder))
+    mine = run.Y_splits_sharded(repo)
+    assert [r.folder.name for r in mine] == [f'Y.{l}' for l in range(rank, repo.L, world)]
+    for split in mine:
+        split.into_K_folds(-2, seed=5)
+        assert run.gpr('gpr', split, is_read=False, is_covariant=False, is_isotropic=False, shard_folds=False) == ['gpr.v.a']
+        if rank == drop_model_of_rank:
+            shutil.rmtree(split.fold_folder(1) / 'gpr.v.a')          # this rank's stored GP of fold 1 goes missing
+    try:
+        done = run.gsa_outputs('gpr', repo, is_isotropic=False)
+        outcome = 'done:' + ','.join(str(n) for n in done)
+    except FileNotFoundError as error:
+        outcome = 'own:' + type(error).__name__
+    except RuntimeError as error:
+        outcome = 'other:' + str(error)
+    Path(repo_folder, f'outcome.{rank}').write_text(outcome)
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+def test_gsa_outputs_with_eight_ranks_reproduces_the_single_process_tables(tmp_path):
+    import pandas as pd
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import oracle_backend
+    from romcomma_amd import _lib
+    from romcomma_amd.user import run
+    keep = (_lib.RcGP, _lib.device_count)
+    oracle_backend.install()
+    try:
+        single = _eight_output_repo(tmp_path / 'single').into_K_folds(-2, seed=5)
+        run.gpr('gpr', single, is_read=False, is_covariant=False, is_isotropic=False)
+        run.gsa('gpr', single, is_covariant=False, is_isotropic=False)
+    finally:
+        _lib.RcGP, _lib.device_count = keep
+    multi = _eight_output_repo(tmp_path / 'multi').into_K_folds(-2, seed=5)
+    mp.spawn(_outputs_worker, args=(8, _free_port(), str(multi.folder), -1), nprocs=8, join=True)
+    outcomes = [(multi.folder / f'outcome.{r}').read_text() for r in range(8)]
+    assert outcomes == ['done:gpr.v.a/gsa/first_order,gpr.v.a/gsa/closed,gpr.v.a/gsa/total'] * 8, outcomes
+    for k in range(2):
+        for kind in ('first_order', 'closed', 'total'):
+            for name in ('S.csv', 'V.csv'):
+                rel = f'fold.{k}/gpr.v.a/gsa/{kind}/{name}'
+                a, b = pd.read_csv(single.folder / rel, index_col=[0, 1]), pd.read_csv(multi.folder / rel, index_col=[0, 1])
+                assert a.shape == b.shape == (64, 4) and list(a.index) == list(b.index) and list(a.columns) == list(b.columns), rel
+                np.testing.assert_allclose(a.values, b.values, rtol=2e-5, atol=3e-6, err_msg=rel)       # the same converged fits; the files carry 6 decimals
+                cross = [i for i, (l0, l1) in enumerate(a.index) if l0 != l1]
+                assert np.any(np.abs(b.values[cross]) > 1e-4), f'{rel}: the cross-output rows are empty'
+    collected = pd.read_csv(multi.folder / 'gpr.v.a' / 'gsa' / 'closed' / 'S.csv')
+    assert collected.shape[0] == 2 * 64 and sorted(collected['fold'].unique()) == [0, 1]
+
+
+def test_a_missing_model_on_one_rank_stops_all_eight_before_the_collectives(tmp_path):
+    """a rank that cannot read its stored GP must not leave the others inside OutputShard's all-gather -- the ranks agree on
+    the local reads of a fold before its first collective. Rank 3 loses its fold-1 model: every rank gets through fold 0 and stops at 1."""
+    import torch.multiprocessing as mp
+    multi = _eight_output_repo(tmp_path / 'multi', N=30).into_K_folds(-2, seed=5)
+    mp.spawn(_outputs_worker, args=(8, _free_port(), str(multi.folder), 3), nprocs=8, join=True)
+    outcomes = [(multi.folder / f'outcome.{r}').read_text() for r in range(8)]
+    assert outcomes[3].startswith('own:FileNotFoundError'), outcomes
+    assert all(out.startswith('other:') and '[3]' in out for r, out in enumerate(outcomes) if r != 3), outcomes
+    assert (multi.folder / 'fold.0' / 'gpr.v.a' / 'gsa' / 'closed' / 'S.csv').exists()
+    assert not (multi.folder / 'fold.1' / 'gpr.v.a' / 'gsa' / 'closed' / 'S.csv').exists()

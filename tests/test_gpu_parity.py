@@ -331,44 +331,36 @@ def test_sobol_error_terms(gpu, L):
         gp.close()
 
 
-@pytest.mark.parametrize('env', [{'RCGP_DIAG': '1'}, {'RCGP_LOOKAHEAD': '0'}, {'RCGP_RESERVE_CUS': '0'}, {'RCGP_OVERLAP_INVERSE': '1'},
-                                 {'RCGP_FINE': '0'}, {'RCGP_FINE': '0', 'RCGP_OVERLAP_INVERSE': '1'},
-                                 {'RCGP_NB': '256', 'RCGP_EXT': '1', 'RCGP_DEPTH': '1'}, {'RCGP_NB': '128', 'RCGP_EXT': '3', 'RCGP_DEPTH': '8'},
-                                 {'RCGP_NB': '384', 'RCGP_DEPTH': '2'}, {'RCGP_OVERLAP_INVERSE': '1', 'RCGP_INV_EVERY': '1', 'RCGP_NB': '256'},
-                                 {'RCGP_EXTEV': '0'}, {'RCGP_SPLIT': '0'}, {'RCGP_PSPLIT': '3'}, {'RCGP_SHORTK': '0'}, {'RCGP_GRAD_ORDER': '1'}, {'RCGP_HEAVY': '1'}, {'RCGP_HEAVY': '1', 'RCGP_HEAVY_RESERVE': '1', 'RCGP_NB': '256'},
-                                 {'RCGP_DLOOP': '1'}, {'RCGP_DLOOP': '2', 'RCGP_NB': '384'}, {'RCGP_PREP_SMALL': '1'}, {'RCGP_BULK_AFTER_PIECE': '1'}, {'RCGP_T2WAIT': '1'}, {'RCGP_PIECES_ON_BULK': '1', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_PSPLIT': '3', 'RCGP_SHORTK': '0', 'RCGP_NB': '256'}, {'RCGP_SPLIT': '0', 'RCGP_EXT': '2', 'RCGP_DEPTH': '4'},
-                                 {'RCGP_EXT': '2'}, {'RCGP_EXT': '6', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_PSPLIT': '0'}, {'RCGP_PSPLIT': '1'},
-                                 {'RCGP_CATCHUP': '4'}, {'RCGP_CATCHUP': '4', 'RCGP_NB': '256', 'RCGP_EXT': '2'},
-                                 {'RCGP_RESERVE_CUS': '8', 'RCGP_RESERVE_ALL': '1', 'RCGP_PIECES_ON_BULK': '1'},
-                                 {'RCGP_RESERVE_CUS': '24', 'RCGP_STREAM_ORDER': '352604'}, {'RCGP_DIAG': '1', 'RCGP_PREP_SMALL': '1', 'RCGP_SHORTK': '0'},
-                                 {'RCGP_CATCHUP': '6', 'RCGP_NB': '384', 'RCGP_EXT': '1'}, {'RCGP_CATCHUP': '9', 'RCGP_NB': '512', 'RCGP_EXT': '3', 'RCGP_DEPTH': '1'}])
-def test_tuning_knobs_do_not_change_results(gpu, env, monkeypatch):
-    """Every run-time variant (register-sweep diagonal kernel, sequential Cholesky, no reserved CUs, overlapped inverse, coarse
-    panel chain, other panel widths / window depths / chain extensions of the fine-grained Cholesky) is the same arithmetic up to
-    rounding: LML, gradient and alpha against the oracle at a size with a ragged last outer panel."""
-    for key, value in env.items():
-        monkeypatch.setenv(key, value)
-    N, M = 1700, 4
-    X, y = o.synthetic_fold(N, M, k=3)
-    ell, var, noise = np.array([0.8, 1.3, 2.0, 2.9]), 1.1, 0.02
-    gp = gpu.RcGP(X, y)
-    gp.set_hyper(ell, var, noise)
-    lml_ref, grad_ref = o.lml_and_grad(X, y, ell, var, noise)
-    lml, grad = gp.lml_grad()
-    assert lml == pytest.approx(lml_ref, rel=1e-10)
-    np.testing.assert_allclose(grad, grad_ref, rtol=1e-7, atol=1e-9 * np.max(np.abs(grad_ref)))
-    assert relmax(gp.k_inv_y(), o.k_inv_y(X, y, ell, var, noise)) < 1e-9
-    gp.close()
+def _knob_case(env, case):
+    """The schedule knobs are read once per process (the first rcgp_create), so every knob set runs in a process of its own:
+    tests/knob_case.py checks against the oracle there and prints one line. One at a time -- the GPU box limits concurrent processes."""
+    import os
+    import subprocess
+    import sys
+    full_env = {**os.environ, **env}
+    done = subprocess.run([sys.executable, str(Path(__file__).resolve().parent / 'knob_case.py'), case], env=full_env, capture_output=True,
+                          text=True, timeout=240)
+    assert done.returncode == 0 and done.stdout.strip().endswith('ok'), (env, done.stdout[-2000:], done.stderr[-2000:])
 
 
-@pytest.mark.parametrize('env', [{}, {'RCGP_NB': '256', 'RCGP_DEPTH': '3'}, {'RCGP_EXT': '1', 'RCGP_DEPTH': '12'}, {'RCGP_CATCHUP': '4'},
-                                 {'RCGP_CATCHUP': '8', 'RCGP_NB': '256', 'RCGP_DEPTH': '3'}, {'RCGP_CATCHUP': '5', 'RCGP_NB': '512', 'RCGP_EXT': '3'},
-                                 {'RCGP_CATCHUP': '12', 'RCGP_NB': '384', 'RCGP_EXT': '2', 'RCGP_DEPTH': '1'}])
-def test_fine_grained_cholesky_factor_many_panels(gpu, env, monkeypatch):
-    """The four-stream Cholesky (diagonal chain, column work, window pieces, bulk update) over 7+ outer panels with a ragged last
-    one: the factor itself, entry by entry, against LAPACK on the oracle's Gram matrix, and w = L^-1 y through the LML."""
-    for key, value in env.items():
-        monkeypatch.setenv(key, value)
+@pytest.mark.parametrize('env', [{'RCGP_LOOKAHEAD': '0'}, {'RCGP_FINE': '0'}, {'RCGP_NB': '256', 'RCGP_EXT': '1', 'RCGP_DEPTH': '1'},
+                                 {'RCGP_NB': '128', 'RCGP_EXT': '3', 'RCGP_DEPTH': '8'}, {'RCGP_NB': '384', 'RCGP_DEPTH': '2'},
+                                 {'RCGP_EXT': '6', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_EXT': '2'}])
+def test_tuning_knobs_do_not_change_results(gpu, env):
+    """Every run-time variant of the factorisation's schedule (sequential Cholesky, coarse panel chain, other panel widths / window
+    depths / chain extensions of the fine-grained Cholesky) is the same arithmetic up to rounding: LML, gradient and alpha against
+    the oracle at a size with a ragged last outer panel."""
+    _knob_case(env, 'evaluation')
+
+
+@pytest.mark.parametrize('env', [{'RCGP_NB': '256', 'RCGP_DEPTH': '3'}, {'RCGP_EXT': '1', 'RCGP_DEPTH': '12'}])
+def test_fine_grained_cholesky_factor_many_panels_other_schedules(gpu, env):
+    _knob_case(env, 'factor')
+
+
+def test_fine_grained_cholesky_factor_many_panels(gpu):
+    """The five-stream Cholesky (diagonal chain, column work, far updates, window pieces, bulk update) over 7+ outer panels with a
+    ragged last one: the factor itself, entry by entry, against LAPACK on the oracle's Gram matrix, and w = L^-1 y through the LML."""
     N, M = 3400, 3
     X, y = o.synthetic_fold(N, M, k=11)
     ell, var, noise = np.array([0.7, 1.5, 2.4]), 0.9, 0.01
@@ -380,6 +372,42 @@ def test_fine_grained_cholesky_factor_many_panels(gpu, env, monkeypatch):
     assert np.all(np.triu(Lc, 1) == 0.0)
     assert gp.lml() == pytest.approx(o.lml(X, y, ell, var, noise), rel=1e-11)
     gp.close()
+
+
+def test_knobs_are_read_once_per_process(gpu, monkeypatch, capfd):
+    """One stream set and one schedule per process: a knob changed after the first rcgp_create is ignored (with a message), so two
+    handles can never run different schedules on the shared streams."""
+    N, M = 900, 3
+    X, y = o.synthetic_fold(N, M, k=2)
+    ell, var, noise = np.array([0.9, 1.4, 2.2]), 1.0, 0.02
+    first = gpu.RcGP(X, y)
+    first.set_hyper(ell, var, noise)
+    before = first.lml_grad()
+    monkeypatch.setenv('RCGP_NB', '128')
+    monkeypatch.setenv('RCGP_FINE', '0')
+    second = gpu.RcGP(X, y)
+    second.set_hyper(ell, var, noise)
+    after = second.lml_grad()
+    assert after[0] == before[0] and np.array_equal(after[1], before[1])           # the same schedule: bit-identical
+    assert 'ignored' in capfd.readouterr().err
+    first.close()
+    second.close()
+
+
+@pytest.mark.parametrize('N,M', [(8192, 5), (16384, 10)])                  # BASELINE configs[1] and [2] (the headline configuration)
+def test_full_size_oracle_comparison(gpu, N, M):
+    """The headline sizes against the oracle itself, not only through properties: LML and its gradient at the fixed benchmark
+    hyper-parameters from ``rcgp_lml_grad`` and from ``oracle.lml_and_grad_blas`` (LAPACK potrf + potri and BLAS-3 sums
+    on the host cores: about 10 s and 25 s on the GPU box). 1e-8 on the LML, 1e-6 of the largest component on the gradient."""
+    X, y = o.synthetic_fold(N, M)
+    ell, var, noise = o.bench_hyper(M)
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(ell, var, noise)
+    lml, grad = gp.lml_grad()
+    gp.close()
+    lml_ref, grad_ref = o.lml_and_grad_blas(X, y, ell, var, noise)
+    assert lml == pytest.approx(lml_ref, rel=1e-8)
+    assert np.max(np.abs(grad - grad_ref)) <= 1e-6 * np.max(np.abs(grad_ref))
 
 
 def test_sobol_error_terms_many_dimensions(gpu):

@@ -1,7 +1,9 @@
-"""Cholesky timing sweep over the run-time knobs (read at rcgp_create): RCGP_FINE, RCGP_NB, RCGP_EXT, RCGP_RESERVE_CUS.
+"""Cholesky timing sweep over the run-time knobs RCGP_LOOKAHEAD, RCGP_FINE, RCGP_NB, RCGP_EXT, RCGP_DEPTH. The library reads them once
+per process, so every (knob set, size) runs in a child process of its own, one after the other.
 Prints potrf time (Gram time subtracted) and the LML (must agree across knobs to ~1e-12 relative).
 
     gpurun -- python tools/potrf_sweep.py 8192 5  16384 10
+    SWEEP_KNOBS='[{}, {"RCGP_NB": "512"}]' python tools/potrf_sweep.py 8192 5
 """
 import os
 import sys
@@ -13,35 +15,22 @@ from romcomma_amd import _lib                                      # noqa: E402
 from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 KNOBS = [
-    {'RCGP_FINE': '0'},
-    {'RCGP_SPLIT': '0', 'RCGP_EXT': '2', 'RCGP_DEPTH': '4'},
     {},
+    {'RCGP_FINE': '0'},
+    {'RCGP_LOOKAHEAD': '0'},
     {'RCGP_DEPTH': '1'},
     {'RCGP_DEPTH': '4'},
     {'RCGP_EXT': '2'},
     {'RCGP_EXT': '6'},
-    {'RCGP_NB': '256'},
     {'RCGP_NB': '512'},
-    {'RCGP_EXTEV': '0'},
-    {'RCGP_PSPLIT': '0'},
-    {'RCGP_PSPLIT': '1'},
-    {'RCGP_DIAG': '1'},
+    {'RCGP_NB': '2048'},
     {},
 ]
 
 
 def run(N, M, knobs, reps=5):
-    saved = {k: os.environ.get(k) for k in knobs}
-    os.environ.update(knobs)
-    try:
-        X, y = synthetic_fold(N, M)
-        gp = _lib.RcGP(X, y)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    X, y = synthetic_fold(N, M)
+    gp = _lib.RcGP(X, y)
     ell, var, noise = bench_hyper(M)
     gp.set_hyper(ell, var, noise)
     lml = gp.lml()
@@ -69,10 +58,14 @@ def run(N, M, knobs, reps=5):
 
 
 if __name__ == '__main__':
+    import json
+    import subprocess
+    if sys.argv[1] == '--one':                                      # child: the knobs are in the environment
+        run(int(sys.argv[2]), int(sys.argv[3]), json.loads(sys.argv[4]))
+        sys.exit(0)
     args = [int(a) for a in sys.argv[1:]] or [8192, 5, 16384, 10]
-    if os.environ.get('SWEEP_KNOBS'):                               # e.g. SWEEP_KNOBS='[{}, {"RCGP_PSPLIT": "2"}, {}]'
-        import json
+    if os.environ.get('SWEEP_KNOBS'):                               # e.g. SWEEP_KNOBS='[{}, {"RCGP_NB": "512"}, {}]'
         KNOBS = json.loads(os.environ['SWEEP_KNOBS'])
     for i in range(0, len(args), 2):
         for kn in KNOBS:
-            run(args[i], args[i + 1], kn)
+            subprocess.run([sys.executable, __file__, '--one', str(args[i]), str(args[i + 1]), json.dumps(kn)], env={**os.environ, **kn}, check=True)
