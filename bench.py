@@ -225,7 +225,8 @@ def main():
             return out
 
     def step(profiled=False):
-        gp = handles[units[counter['s']]]
+        unit = units[counter['s']]
+        gp = handles[unit]
         counter['s'] += 1
         fit = fit_lbfgsb(Timed(gp), 5.0 * np.ones(M), 2.0, 0.02)
         counter['nfev'] += int(fit['nfev'])
@@ -234,7 +235,7 @@ def main():
         t_sobol = time.perf_counter()
         V = gp.sobol_closed(slices)
         counter['sobol_s'] += time.perf_counter() - t_sobol
-        row = np.concatenate([sobol_indices(V, M), fit['lengthscales'], [fit['variance'], fit['noise'], fit['log_marginal'], fit['nfev']]])
+        row = np.concatenate([sobol_indices(V, M), fit['lengthscales'], [fit['variance'], fit['noise'], fit['log_marginal'], fit['nfev'], unit]])
         table = dist.all_gather_rows(row[None, :], world, [rank])      # the one collective: every rank's indices
         last.update(fit=fit, V=V, table=table)
 
@@ -307,7 +308,9 @@ def main():
                        'ms_per_evaluation_incl_host': 1e3 * elapsed / max(nfev_total, 1),
                        'ms_per_step_inside_library_calls': 1e3 * (counter['lib_s'] + counter['sobol_s']) / args.steps,
                        'ms_per_step_host_only': 1e3 * (elapsed - counter['lib_s'] - counter['sobol_s']) / args.steps, 'parallelism': f'{args.shard[:-1]}-per-gpu x{world}',
-                       'log_marginal': last['fit']['log_marginal']},
+                       'log_marginal': last['fit']['log_marginal'],
+                       'gathered_rows_last_step': int(np.sum(~np.isnan(last['table']).any(axis=1))),
+                       'units_last_step': [int(u) for u in last['table'][:, -1]]},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'traffic_source': (f'{traffic_file}: rocprofv3 --pmc pass of the same workload and build, NOT measured in this run' if traffic_file else None),

@@ -611,7 +611,8 @@ __global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld
                                      double* __restrict__ partial) {
   constexpr int ZL = 2 * 128 * LZ;
   constexpr int NW = 2 * WN;                                  // waves per workgroup
-  __shared__ double lds[(GEMM_LDS > ZL ? GEMM_LDS : ZL) + NW * (RC_MAX_M + 2)];
+  constexpr int ZA = ZL + 4 * 128;                            // + alpha and sq of the tile's 128 rows and 128 columns
+  __shared__ double lds[(GEMM_LDS > ZA ? GEMM_LDS : ZA) + NW * (RC_MAX_M + 2)];
   int ti, tj;
   tri_decode(blockIdx.x, ti, tj);
   const int64_t kstart = (int64_t)ti * 128;
@@ -622,49 +623,81 @@ __global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld
   RC_LANE_VARS(WN)
   double* zi = lds;
   double* zj = lds + 128 * LZ;
-  double* red = lds + (GEMM_LDS > ZL ? GEMM_LDS : ZL);
+  double* ars = lds + ZL;                                     // alpha_i[128], sq_i[128], alpha_j[128], sq_j[128]
+  double* red = lds + (GEMM_LDS > ZA ? GEMM_LDS : ZA);
   for (int e = threadIdx.x; e < 128 * M; e += 128 * WN) {
     const int rr = e / M, m = e - rr * M;
     zi[rr * LZ + m] = Z[((int64_t)ti * 128 + rr) * M + m];
     zj[rr * LZ + m] = Z[((int64_t)tj * 128 + rr) * M + m];
+  }
+  if (threadIdx.x < 128) {                                    // (through LDS: no 64-bit address arithmetic per element in the epilogue)
+    ars[threadIdx.x] = alpha[(int64_t)ti * 128 + threadIdx.x];
+    ars[128 + threadIdx.x] = sq[(int64_t)ti * 128 + threadIdx.x];
+    ars[256 + threadIdx.x] = alpha[(int64_t)tj * 128 + threadIdx.x];
+    ars[384 + threadIdx.x] = sq[(int64_t)tj * 128 + threadIdx.x];
   }
   __syncthreads();
   double gvar = 0.0, gnoise = 0.0;
   double aj[NI_], sj[NI_];
 #pragma unroll
   for (int ni = 0; ni < NI_; ++ni) {
-    const int64_t j = (int64_t)tj * 128 + wc_ + 16 * ni + fr_;
-    aj[ni] = alpha[j];
-    sj[ni] = sq[j];
+    aj[ni] = ars[256 + wc_ + 16 * ni + fr_];
+    sj[ni] = ars[384 + wc_ + 16 * ni + fr_];
   }
+  const int row0 = ti * 128, col0 = tj * 128;                 // (N < 2^31)
+  // One 16-row group (8 elements per lane) at a time, its dot products accumulated over m in 8 registers: written as 32 independent
+  // element evaluations the compiler jams the 32 dynamic-length dot loops together and spills 260 registers per lane (704 B of
+  // scratch: 4.4 GB of HBM writes per launch at C2, profiles/r02_pmc_c2.json).
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < 4; ++mi) {
+    double dot[4][NI_];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ni = 0; ni < NI_; ++ni) dot[r][ni] = 0.0;
+    // (the trip count passes through an opaque statement together with the running sum of the previous group: otherwise the compiler
+    // runs the four dot loops first, parks 32 dot products in scratch memory, and evaluates the 32 exps afterwards)
+    int mcount = M;
+    asm volatile("" : "+s"(mcount), "+v"(gvar));
+#pragma unroll 1
+    for (int m = 0; m < mcount; ++m) {
+      double zr[4], zc[NI_];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zr[r] = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
+#pragma unroll
+      for (int ni = 0; ni < NI_; ++ni) zc[ni] = zj[(wc_ + 16 * ni + fr_) * LZ + m];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ni = 0; ni < NI_; ++ni) dot[r][ni] = fma(zr[r], zc[ni], dot[r][ni]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wr_ + 16 * mi + 4 * r + fq_;
-      const int64_t i = (int64_t)ti * 128 + row;
-      const double ai = alpha[i], si = sq[i];
+      const int i = row0 + row;
+      const double ai = ars[row], si = ars[128 + row];
 #pragma unroll
       for (int ni = 0; ni < NI_; ++ni) {
         const int col = wc_ + 16 * ni + fr_;
-        const int64_t j = (int64_t)tj * 128 + col;
-        double dot = 0.0;
-        for (int m = 0; m < M; ++m) dot = fma(zi[row * LZ + m], zj[col * LZ + m], dot);
-        const double kij = var * rc_exp(si + sj[ni] + dot);
+        const int j = col0 + col;
+        const double kij = var * rc_exp(si + sj[ni] + dot[r][ni]);
         const double wij = ai * aj[ni] - acc[mi][ni][r];
-        const bool valid = (i < N) && (j <= i);
+        const bool valid = (i < (int)N) && (j <= i);
         const double wgt = valid ? (j == i ? 1.0 : 2.0) : 0.0;
         const double wk = wgt * wij * kij;
         acc[mi][ni][r] = wk;
         gvar += wk;
         if (valid && j == i) gnoise += wij;
+        __builtin_amdgcn_sched_barrier(0);                    // (one exp at a time: interleaving all eight of a group costs ~100 registers)
       }
     }
+  }
   auto wave_sum = [](double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
   };
+#pragma unroll 1
   for (int m = 0; m < M; ++m) {
     double g = 0.0;
 #pragma unroll

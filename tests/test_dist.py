@@ -232,3 +232,23 @@ def test_a_missing_model_on_one_rank_stops_all_eight_before_the_collectives(tmp_
     assert all(out.startswith('other:') and '[3]' in out for r, out in enumerate(outcomes) if r != 3), outcomes
     assert (multi.folder / 'fold.0' / 'gpr.v.a' / 'gsa' / 'closed' / 'S.csv').exists()
     assert not (multi.folder / 'fold.1' / 'gpr.v.a' / 'gsa' / 'closed' / 'S.csv').exists()
+
+
+def test_bench_eight_ranks_rehearsal_over_gloo():
+    """The driver's N = 8 command line (torch.distributed.run, eight ranks) at a toy size: one JSON line from rank 0, whole-job value over
+    all eight ranks, and in the last timed step the eight ranks hold the eight different folds of the split (fold (r + s) mod 8)."""
+    import json
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1', '--master-port',
+           str(_free_port()), str(ROOT / 'tests' / 'bench_cpu_rehearsal.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--rows', '64', '--dims', '3',
+           '--backend', 'gloo']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT), env={**os.environ, 'OMP_NUM_THREADS': '1'})
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and 'cpu_baseline' not in d
+    assert d['value'] == pytest.approx(8 * 64 * 2 / (d['ms_per_step'] * 2e-3), rel=1e-9)
+    assert 'x8' in d['config']['parallelism'] and d['config']['gathered_rows_last_step'] == 8
+    assert sorted(d['config']['units_last_step']) == list(range(8))                  # rank r: fold (r + 1) mod 8 in timed step 1
+    assert d['config']['units_last_step'] == [(r + 1) % 8 for r in range(8)]

@@ -51,10 +51,10 @@ def make_repo(folder: Path, N=200, M=3, seed=0):
 
 def test_two_ranks_shard_folds(gpu, tmp_path):
     from romcomma_amd.user import run
-    single = make_repo(tmp_path / 'single').into_K_folds(-4, seed=5)
+    single = make_repo(tmp_path / 'single').into_K_folds(-4, seed=6)
     run.gpr('gpr', single, is_read=False, is_covariant=False, is_isotropic=False)
     run.gsa('gpr', single, is_covariant=False, is_isotropic=False)
-    multi = make_repo(tmp_path / 'multi').into_K_folds(-4, seed=5)
+    multi = make_repo(tmp_path / 'multi').into_K_folds(-4, seed=6)
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
     port = _free_port()

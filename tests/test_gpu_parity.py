@@ -197,6 +197,34 @@ def test_not_positive_definite_is_reported(gpu):
     gp.close()
 
 
+def test_fit_that_runs_into_a_singular_gram_matrix_stops_where_lapack_stops(gpu, tmp_path):
+    """Found by the host tests of round 3: on this fold (seed 5, fold 1 of a 4-fold split of 200 smooth rows) the L-BFGS-B line search
+    reaches hyper-parameters at which K + noise I is not positive definite in fp64. The reference would get TensorFlow's Cholesky error
+    there; here the library must report it (not return a wrong LML) and name the SAME leading minor as LAPACK at the same point."""
+    import pandas as pd
+    import scipy.linalg
+    from romcomma_amd.data.storage import Fold, Repository
+    from romcomma_amd.gpr.optimize import fit_lbfgsb
+    rng = np.random.default_rng(0)
+    U = rng.random((200, 3))
+    y = np.sin(2 * np.pi * U[:, 0]) + 0.7 * U[:, 1] ** 2 + 0.05 * U[:, 2] + 0.02 * rng.standard_normal(200)
+    columns = pd.MultiIndex.from_tuples([('X', f'X.{m}') for m in range(3)] + [('Y', 'Y.0')])
+    repo = Repository.from_df(tmp_path / 'repo', pd.DataFrame(np.concatenate([U, y[:, None]], axis=1), columns=columns)).into_K_folds(-4, seed=5)
+    fold = Fold(repo, 1)
+    X, Y = np.ascontiguousarray(fold.X.values), np.ascontiguousarray(fold.Y.values[:, 0])
+    gp = gpu.RcGP(X, Y)
+    seen = []
+    set_hyper = gp.set_hyper
+    gp.set_hyper = lambda ell, var, noise: (seen.append((np.array(ell), var, noise)), set_hyper(ell, var, noise))[1]
+    with pytest.raises(gpu.NotPositiveDefiniteError) as failure:
+        fit_lbfgsb(gp, 5.0 * np.ones(3), 2.0, 0.02)
+    gp.close()
+    ell, var, noise = seen[-1]
+    with pytest.raises(np.linalg.LinAlgError) as lapack:
+        scipy.linalg.cholesky(o.noisy_gram(X, ell, var, noise), lower=True)
+    assert f'{failure.value.k}-th leading minor' in str(lapack.value), (failure.value.k, str(lapack.value))
+
+
 def test_not_positive_definite_inside_the_multi_stream_cholesky(gpu):
     """The same failure deep inside the four-stream factorisation (4 outer panels): the duplicate of row 700 sits at row 1500, so
     the first non-positive pivot is found by a diagonal kernel of the third panel, long after the chain, the column work and the
