@@ -44,7 +44,8 @@ extern "C" __attribute__((visibility("default"))) int rcgp_debug_diag_spans(long
 // LDS of the two diagonal-block kernels (dynamic): S[128][LS] -- L in its lower triangle (and, in the inverse kernel, the off-diagonal
 // blocks of X = L^-1 TRANSPOSED in the upper triangle) -- then Xd[8][16][XS] (the 16x16 diagonal-block inverses), rsd[128] (1 / L_ii),
 // rv[128] (right-hand side), pcol[32] (two pivot-column lines), lt[256] (transposed copy of the current diagonal 16-block).
-#define LS 130
+#define LS 129          // ODD: a row per lane (the pivot block's loads / stores) and a row per fragment lane (the MFMA operand reads) both
+                        // fall on 16 different bank pairs (130: lanes r and r + 8 collide)
 #define XS 18
 #define RC_DIAG_LDS ((size_t)(128 * LS + 8 * 16 * XS + 256 + 32 + 256) * sizeof(double))
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ void pivot16(double* blk, double* Xdc, double* rsdc, 
   pcol[r] = a[0];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  double dv = rl_d(a[0], 0);
+  double dv = rl_d(a[0], 0), dsave = 1.0;
   int bad = 0;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -112,9 +113,18 @@ __device__ __forceinline__ void pivot16(double* blk, double* Xdc, double* rsdc, 
     }
 #pragma unroll
     for (int c2 = j + 2; c2 < 16; ++c2) a[c2] = __builtin_fma(-tj, ln[c2], a[c2]);
-    const double rs = rc_rsqrt(dd);
-    a[j] *= rs;                                                  // L[r][j]
-    if (lane == j) rsdc[j] = rs;
+    dsave = (r == j) ? dd : dsave;                               // lane j keeps pivot j
+  }
+  // 1 / sqrt(d_j) for all sixteen pivots at once (lane j its own: one Newton-refined rsqrt per lane instead of one per pivot and wave),
+  // handed round through rsd, then the columns scaled: L[r][j] = A[r][j] / sqrt(d_j)
+  if (lane < 16) rsdc[r] = rc_rsqrt(dsave);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double2 v = *reinterpret_cast<const double2*>(rsdc + 2 * q);
+    a[2 * q] *= v.x;
+    a[2 * q + 1] *= v.y;
   }
   if (stamp) RC_T(26);
   if (bad != 0 && lane == 0) atomicCAS(info, 0, (int)(row0 + bad));

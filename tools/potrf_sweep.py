@@ -12,6 +12,9 @@ from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from romcomma_amd import _lib                                      # noqa: E402
+import os as _os
+if _os.environ.get('RCGP_DEV_LIB'):
+    _lib.LIB_PATH = Path(_os.environ['RCGP_DEV_LIB']).resolve()
 from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 KNOBS = [
