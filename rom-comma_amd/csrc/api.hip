@@ -28,7 +28,7 @@ RC_API int rcgp_device_count(void) {
 // ONE set of five streams per device, created by the first rcgp_create on that device and shared by every handle of the process on
 // it until process exit -- whatever the environment says later. Every stream is a hardware queue that the runtime keeps anyway, and the
 // multi-stream Cholesky slows down by a quarter once a few more queues than its own exist (three handles with streams of their own:
-// 34 -> 43 ms at C2; idle queues created BETWEEN the library's: 33 -> 75 ms; DESIGN.md section 4, "stream placement"). Handles are used
+// 34 -> 43 ms at C2; idle queues created BETWEEN the library's: 33 -> 75 ms; DESIGN.md Appendix A.2, "stream placement"). Handles are used
 // one call at a time by their owner, so sharing the streams only orders the work of different handles of one device behind each
 // other. Creation order is fixed (main, chain, column work, far updates, bulk): with it the two streams that carry long K = NB
 // kernels share a dispatch pipe and the chain's three have one each, the best of the 20 orders measured in round 2.

@@ -604,7 +604,7 @@ int rc_launch_trtri_X(rcgp_handle_s* h, int64_t s, int pair0, int npairs) {
 // K^-1 is never written: each lower tile is reduced in the epilogue to M+2 partial sums (row blockIdx of h->partial).
 // ---------------------------------------------------------------------------------------------------------------------
 // Tiles go out in row order of the lower triangle, heaviest k-ranges first by construction of tri_decode's enumeration (an 8 x 8
-// super-block order per XCD was measured: HBM reads -7 %, time +13 % -- DESIGN.md).
+// super-block order per XCD was measured: HBM reads -7 %, time +13 % -- DESIGN.md Appendix A.3).
 template <int LZ, int WN>
 __global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld, int64_t Np, int64_t N, int M, const double* __restrict__ Z,
                                      const double* __restrict__ sq, const double* __restrict__ alpha, double var,
@@ -645,9 +645,17 @@ __global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld
     sj[ni] = ars[384 + wc_ + 16 * ni + fr_];
   }
   const int row0 = ti * 128, col0 = tj * 128;                 // (N < 2^31)
-  // One 16-row group (8 elements per lane) at a time, its dot products accumulated over m in 8 registers: written as 32 independent
-  // element evaluations the compiler jams the 32 dynamic-length dot loops together and spills 260 registers per lane (704 B of
-  // scratch: 4.4 GB of HBM writes per launch at C2, profiles/r02_pmc_c2.json).
+  auto wave_sum = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  if (lane_ < M) red[wave_ * (RC_MAX_M + 2) + lane_] = 0.0;    // this wave's M gradient sums, accumulated group by group (M <= 64 lanes)
+  // One 16-row group (8 elements per lane) at a time, START TO END: its dot products in 8 registers, its eight W.K values, and at once
+  // their M gradient sums (reduced over the wave and added into the wave's LDS slots by lane 0) -- so the group's accumulators are dead
+  // when the next group starts. Written as 32 independent element evaluations followed by one pass per m over all 32, the compiler
+  // jams the 32 dynamic-length dot loops together and keeps everything alive: 260 registers per lane in scratch (704 B: 4.4 GB of HBM
+  // writes per launch at C2, profiles/r02_pmc_c2.json). The epilogue's instruction count is irrelevant next to a tile's main loop.
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     double dot[4][NI_];
@@ -671,6 +679,7 @@ __global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld
 #pragma unroll
         for (int ni = 0; ni < NI_; ++ni) dot[r][ni] = fma(zr[r], zc[ni], dot[r][ni]);
     }
+    double wk[4][NI_];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wr_ + 16 * mi + 4 * r + fq_;
@@ -684,35 +693,26 @@ __global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld
         const double wij = ai * aj[ni] - acc[mi][ni][r];
         const bool valid = (i < (int)N) && (j <= i);
         const double wgt = valid ? (j == i ? 1.0 : 2.0) : 0.0;
-        const double wk = wgt * wij * kij;
-        acc[mi][ni][r] = wk;
-        gvar += wk;
+        wk[r][ni] = wgt * wij * kij;
+        gvar += wk[r][ni];
         if (valid && j == i) gnoise += wij;
-        __builtin_amdgcn_sched_barrier(0);                    // (one exp at a time: interleaving all eight of a group costs ~100 registers)
       }
     }
-  }
-  auto wave_sum = [](double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-  };
 #pragma unroll 1
-  for (int m = 0; m < M; ++m) {
-    double g = 0.0;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int m = 0; m < mcount; ++m) {
+      double g = 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const double zim = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
 #pragma unroll
         for (int ni = 0; ni < NI_; ++ni) {
           const double d = zim - zj[(wc_ + 16 * ni + fr_) * LZ + m];
-          g = fma(acc[mi][ni][r], d * d, g);
+          g = fma(wk[r][ni], d * d, g);
         }
       }
-    g = wave_sum(g);
-    if (lane_ == 0) red[wave_ * (RC_MAX_M + 2) + m] = g;
+      g = wave_sum(g);
+      if (lane_ == 0) red[wave_ * (RC_MAX_M + 2) + m] += g;
+    }
   }
   gvar = wave_sum(gvar);
   gnoise = wave_sum(gnoise);
@@ -768,7 +768,8 @@ __global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t
   constexpr int ZL = 2 * 128 * LZ;
   constexpr int NW = 2 * WN;
   constexpr int RW = 2 * RC_MAX_M + 2;
-  __shared__ double lds[(GEMM_LDS > ZL ? GEMM_LDS : ZL) + NW * RW];
+  constexpr int ZA = ZL + 4 * 128;                            // + alpha and sq of the tile's 128 rows and 128 columns
+  __shared__ double lds[(GEMM_LDS > ZA ? GEMM_LDS : ZA) + NW * RW];
   int ti, tj;
   tri_decode(blockIdx.x, ti, tj);
   v4d acc[4][Geo<WN>::NI];
@@ -777,11 +778,18 @@ __global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t
   RC_LANE_VARS(WN)
   double* zi = lds;
   double* zj = lds + 128 * LZ;
-  double* red = lds + (GEMM_LDS > ZL ? GEMM_LDS : ZL);
+  double* ars = lds + ZL;                                     // alpha_i[128], sq_i[128], alpha_j[128], sq_j[128]
+  double* red = lds + (GEMM_LDS > ZA ? GEMM_LDS : ZA);
   for (int e = threadIdx.x; e < 128 * M; e += 128 * WN) {
     const int rr = e / M, m = e - rr * M;
     zi[rr * LZ + m] = Z[((int64_t)ti * 128 + rr) * M + m];
     zj[rr * LZ + m] = Z[((int64_t)tj * 128 + rr) * M + m];
+  }
+  if (threadIdx.x < 128) {                                    // (through LDS: no 64-bit address arithmetic per element in the epilogue)
+    ars[threadIdx.x] = alpha[(int64_t)ti * 128 + threadIdx.x];
+    ars[128 + threadIdx.x] = sq[(int64_t)ti * 128 + threadIdx.x];
+    ars[256 + threadIdx.x] = alpha[(int64_t)tj * 128 + threadIdx.x];
+    ars[384 + threadIdx.x] = sq[(int64_t)tj * 128 + threadIdx.x];
   }
   __syncthreads();
   const int bi = ti / tb, bj = tj / tb;
@@ -792,43 +800,61 @@ __global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t
   double aj[NI_], sj[NI_];
 #pragma unroll
   for (int ni = 0; ni < NI_; ++ni) {
-    const int64_t j = (int64_t)tj * 128 + wc_ + 16 * ni + fr_;
-    aj[ni] = alpha[j];
-    sj[ni] = sq[j];
+    aj[ni] = ars[256 + wc_ + 16 * ni + fr_];
+    sj[ni] = ars[384 + wc_ + 16 * ni + fr_];
   }
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = wr_ + 16 * mi + 4 * r + fq_;
-      const int64_t i = (int64_t)ti * 128 + row;
-      const double ai = alpha[i], si = sq[i];
-#pragma unroll
-      for (int ni = 0; ni < NI_; ++ni) {
-        const int col = wc_ + 16 * ni + fr_;
-        const int64_t j = (int64_t)tj * 128 + col;
-        double dot = 0.0;
-        for (int m = 0; m < M; ++m) dot = fma(zi[row * LZ + m], zj[col * LZ + m], dot);
-        const double eij = rc_exp(si + sj[ni] + dot);
-        const double wij = ai * aj[ni] - acc[mi][ni][r];
-        const int64_t ii = i - ioff, jj = j - joff;
-        const bool valid = (ii < N) && (jj < N) && (j <= i);
-        const double wgt = valid ? (j == i ? 1.0 : 2.0) : 0.0;
-        const double we = wgt * wij * eij;
-        acc[mi][ni][r] = var * we;
-        ge += we;
-        if (ii == jj) gdiag += wgt * wij;
-      }
-    }
   auto wave_sum = [](double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
   };
-  for (int m = 0; m < M; ++m) {
-    double ga = 0.0, gb = 0.0;
+  for (int m = lane_; m < 2 * M; m += 64) red[wave_ * RW + m] = 0.0;   // this wave's 2M gradient sums, accumulated group by group
+  // one 16-row group at a time, start to end, as in k_grad (its accumulators are dead when the next group starts: no scratch)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < 4; ++mi) {
+    double dot[4][NI_];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ni = 0; ni < NI_; ++ni) dot[r][ni] = 0.0;
+    int mcount = M;
+    asm volatile("" : "+s"(mcount), "+v"(ge));
+#pragma unroll 1
+    for (int m = 0; m < mcount; ++m) {
+      double zr[4], zc[NI_];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zr[r] = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
+#pragma unroll
+      for (int ni = 0; ni < NI_; ++ni) zc[ni] = zj[(wc_ + 16 * ni + fr_) * LZ + m];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ni = 0; ni < NI_; ++ni) dot[r][ni] = fma(zr[r], zc[ni], dot[r][ni]);
+    }
+    double wk[4][NI_];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr_ + 16 * mi + 4 * r + fq_;
+      const int i = ti * 128 + row;
+      const double ai = ars[row], si = ars[128 + row];
+#pragma unroll
+      for (int ni = 0; ni < NI_; ++ni) {
+        const int col = wc_ + 16 * ni + fr_;
+        const int j = tj * 128 + col;
+        const double eij = rc_exp(si + sj[ni] + dot[r][ni]);
+        const double wij = ai * aj[ni] - acc[mi][ni][r];
+        const int ii = i - (int)ioff, jj = j - (int)joff;
+        const bool valid = (ii < (int)N) && (jj < (int)N) && (j <= i);
+        const double wgt = valid ? (j == i ? 1.0 : 2.0) : 0.0;
+        const double we = wgt * wij * eij;
+        wk[r][ni] = var * we;
+        ge += we;
+        if (ii == jj) gdiag += wgt * wij;
+      }
+    }
+#pragma unroll 1
+    for (int m = 0; m < mcount; ++m) {
+      double ga = 0.0, gb = 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const double zim = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
@@ -836,16 +862,17 @@ __global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t
         for (int ni = 0; ni < NI_; ++ni) {
           const double zjm = zj[(wc_ + 16 * ni + fr_) * LZ + m];
           const double d = zim - zjm;
-          const double wd = acc[mi][ni][r] * d;
+          const double wd = wk[r][ni] * d;
           ga = fma(wd, same ? d : zim, ga);
           gb = fma(wd, same ? 0.0 : zjm, gb);
         }
       }
-    ga = wave_sum(ga);
-    gb = wave_sum(gb);
-    if (lane_ == 0) {
-      red[wave_ * RW + m] = ga;
-      red[wave_ * RW + M + m] = gb;
+      ga = wave_sum(ga);
+      gb = wave_sum(gb);
+      if (lane_ == 0) {
+        red[wave_ * RW + m] += ga;
+        red[wave_ * RW + M + m] += gb;
+      }
     }
   }
   ge = wave_sum(ge);

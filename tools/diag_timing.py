@@ -1,4 +1,4 @@
-"""Phase breakdown of the diagonal-block kernel (k_diag2) from in-kernel wall_clock64 stamps. Needs a dev build of the
+"""Phase breakdown of the diagonal-block kernel (k_diag_factor) from in-kernel wall_clock64 stamps. Needs a dev build of the
 library: make -C rom-comma_amd/csrc clean all EXTRA=-DRC_DIAG_TIMING (never the shipped build)."""
 import ctypes
 import sys
@@ -28,9 +28,9 @@ names = {1: 'load', 2: 'pivot block 0'}
 for c in range(8):
     names[3 + 2 * c] = f'panel {c}'
     names[4 + 2 * c] = f'trailing {c} + pivot {c + 1}'
-names.update({19: 'store L, logdiag', 20: 'inverse level 16', 21: 'inverse level 32', 22: 'inverse level 64', 23: 'store X, w'})
-print('pivot block 0 inside: load rows %.2f, 16 pivots %.2f, publish %.2f, inverse %.2f us' % tuple((t[k+1]-t[k])/100.0 for k in (24,25,26,27)))
-print('around pivot block 0: before call t=%.2f, entry %.2f, rows loaded %.2f, pivots done %.2f, published %.2f, inverse done %.2f, function end %.2f, returned %.2f' % tuple((t[k]-t[0])/100.0 for k in (29,24,25,26,27,28,30,31)))
+names.update({19: 'store L, logdiag, diagonal-block inverses, w_j'})
+print('pivot block 0 inside (pivot16): load rows %.2f, 16 pivots + scaling %.2f, publish L and its transpose %.2f, inverse %.2f, store it %.2f us'
+      % tuple((t[b] - t[a]) / 100.0 for a, b in ((24, 25), (25, 26), (26, 27), (27, 28), (28, 30))))
 prev = 0.0
 for i in sorted(names):
     if t[i] == 0:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel-trace timeline of the Cholesky's panel chain at one size, for each value of a knob (run through gpurun from the repo root):
-#   gpurun -- bash tools/timeline.sh 4096 5 RCGP_PSPLIT 3 2
+#   gpurun -- bash tools/timeline.sh 4096 5 RCGP_NB 512 1024
 # Writes gpurun_out/tl_<N>_<knob><value>.txt (tools/chain_timeline.py on the trace of tools/potrf_once.py).
 set -o pipefail
 N=$1; M=$2; KNOB=$3; shift 3
