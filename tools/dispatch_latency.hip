@@ -12,13 +12,14 @@
 #include <vector>
 #define CK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(err_)); return 1; } } while (0)
 
-__global__ void __launch_bounds__(512, 2) k_hog(int ticks, double* sink, int jitter) {
+template <int PAD>
+__global__ void __launch_bounds__(512, 4) k_hog(int ticks, double* sink, int jitter) {      // (512, 4): at most 128 VGPRs, as the update kernels
   if (jitter == 1) ticks += (ticks * (int)(blockIdx.x % 8)) / 16;  // tiles of unequal length: up to +44 %
   if (jitter == 2 && blockIdx.x < 512) {                          // equal tiles, first generation staggered over one tile time
     const long long until = wall_clock64() + (long long)((blockIdx.x * 37u) & 63u) * ticks / 64;
     while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
   }
-  __shared__ double pad[8192];                               // 64 KB: two workgroups per CU
+  __shared__ double pad[PAD];                                // 8192 doubles = 64 KB: two workgroups per CU; 10496 = 82 KB: ONE per CU
   asm volatile("v_mov_b32 v127, 0" ::: "v127");             // 128 VGPRs: two workgroups fill the register file as well
   pad[threadIdx.x] = (double)threadIdx.x;
   const long long t0 = wall_clock64();                       // 100 MHz
@@ -47,6 +48,7 @@ static double now_us() {
 
 int main(int argc, char** argv) {
   const int tile_us = argc > 1 ? atoi(argv[1]) : 260, gens = argc > 2 ? atoi(argv[2]) : 12, jitter = argc > 3 ? atoi(argv[3]) : 0;
+  const int one_per_cu = argc > 4 ? atoi(argv[4]) : 0;       // 1: the hog's workgroups take 82 KB of LDS, so a CU holds ONE and keeps a slot free
   int lo, hi;
   CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
   hipStream_t hogA, probeS, s3, s4, hogB;                      // creation ranks 1..5 after the null stream: hogA and hogB share a pipe (1 and 5)
@@ -66,7 +68,9 @@ int main(int argc, char** argv) {
                           {512, 10240, 64, "8 waves, 10 KB, 64 regs"},      {512, 10240, 128, "8 waves, 10 KB, 128 regs (k_diag)"},
                           {256, 10240, 128, "4 waves, 10 KB, 128 regs"},    {256, 10240, 256, "4 waves, 10 KB, 256 regs"},
                           {512, 50688, 128, "8 waves, 49.5 KB, 128 regs"},  {256, 50688, 128, "4 waves, 49.5 KB, 128 regs"},
-                          {512, 141312, 128, "8 waves, 138 KB (k_prep1)"},  {512, 153600, 128, "8 waves, 150 KB (k_diag2)"}};
+                          {512, 141312, 128, "8 waves, 138 KB (k_prep1)"},  {512, 153600, 128, "8 waves, 150 KB (k_diag2)"},
+                          {256, 30720, 256, "4 waves, 30 KB, 256 regs (slim diag)"}, {512, 78848, 128, "8 waves, 77 KB, 128 regs (k_trsm_subst)"},
+                          {512, 75776, 128, "8 waves, 74 KB, 128 regs (update)"}};
   auto launch_probe = [&](const Shape& sh) {
     if (sh.regs == 64) hipLaunchKernelGGL(k_probe<64>, dim3(1), dim3(sh.threads), sh.lds, probeS, stamp, 500);
     else if (sh.regs == 128) hipLaunchKernelGGL(k_probe<128>, dim3(1), dim3(sh.threads), sh.lds, probeS, stamp, 500);
@@ -86,8 +90,14 @@ int main(int argc, char** argv) {
       std::sort(idle.begin(), idle.end());
       CK(hipDeviceSynchronize());
       const double h0 = now_us();
-      hipLaunchKernelGGL(k_hog, dim3(512 * gens), dim3(512), 0, hogA, tile_us * 100, (double*)nullptr, jitter);
-      if (nhog == 2) hipLaunchKernelGGL(k_hog, dim3(512 * gens), dim3(512), 0, hogB, tile_us * 100, (double*)nullptr, jitter);
+      const int hog_gens = one_per_cu ? gens / 2 : gens;       // the same wall time: half as many workgroups run at once
+      if (one_per_cu) {
+        hipLaunchKernelGGL(k_hog<10496>, dim3(512 * hog_gens), dim3(512), 0, hogA, tile_us * 100, (double*)nullptr, jitter);
+        if (nhog == 2) hipLaunchKernelGGL(k_hog<10496>, dim3(512 * hog_gens), dim3(512), 0, hogB, tile_us * 100, (double*)nullptr, jitter);
+      } else {
+        hipLaunchKernelGGL(k_hog<8192>, dim3(512 * gens), dim3(512), 0, hogA, tile_us * 100, (double*)nullptr, jitter);
+        if (nhog == 2) hipLaunchKernelGGL(k_hog<8192>, dim3(512 * gens), dim3(512), 0, hogB, tile_us * 100, (double*)nullptr, jitter);
+      }
       const double total = (double)tile_us * gens * nhog;
       while (now_us() - h0 < 0.8 * total) {
         const double t0 = now_us();
