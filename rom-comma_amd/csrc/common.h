@@ -14,6 +14,9 @@
 #define RC_MAX_L 16            // most outputs of one covariant GP
 #define RC_SCAL_ELEMS 256      // h->scal: [0,2) LML sums, [8, 8+M+2) gradient sums, [RC_SCAL_INFO] the Cholesky status word
 #define RC_SCAL_INFO 128
+#ifndef RC_TRTRI_HALF_TILES
+#define RC_TRTRI_HALF_TILES 1024
+#endif
 #define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -51,6 +54,7 @@ struct rcgp_handle_s {
   int64_t nb_outer = RC_NB_OUTER;    // RCGP_NB: outer panel width
   int chain_depth = 2;               // RCGP_DEPTH >= 1: column panels updated by their own kernels ahead of the bulk trailing update
   int chain_ext = 4;                 // RCGP_EXT >= 1: 128-blocks past its own panel that a chain step keeps up to date
+  int64_t trtri_half_tiles = RC_TRTRI_HALF_TILES;   // L^-1 launches of at most this many 128^2 tiles run on 64 x 128 half tiles (gemm.hip)
   int64_t N = 0, Np = 0;       // training rows per output; rows of the whole system, L * Nb
   int64_t Nb = 0;              // N padded to a multiple of RC_TILE: rows of one output block (Nb == Np when L == 1)
   int L = 1;                   // outputs modelled jointly (covariant GP, rcgp_create_mo): system row a = l * Nb + n

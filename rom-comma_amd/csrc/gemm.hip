@@ -577,11 +577,123 @@ __global__ void RC_BOUNDS(WN) k_trtri_X(double* __restrict__ W, const double* __
   acc_store<WN>(acc, W + (rowC + (int64_t)ti * 128) * ld + colA + (int64_t)tj * 128, ld);
 }
 
+// The same two products on 64 x 128 HALF tiles (512 threads, waves 2x4, 32x32 per wave): for the levels whose launches have too few
+// tiles to balance -- a launch of <= 2 generations of 128^2 tiles with k-ranges from 128 to s lasts as long as its LONGEST tile
+// (C1, s = 2048: 512 tiles, 0.53 ms for 0.28 ms of work); twice as many workgroups of half the length pack behind each other
+// (0.33 ms; L^-1 at N = 8192 3.90 -> 3.39 ms, at N = 4096 1.13 -> 0.72, C2 22.9 -> 22.5). Pairing a long and a short half tile in one
+// workgroup (equal k totals) on top of that: no further gain, 12-24 spilled registers -- not kept.
+template <bool NEG>
+__device__ __forceinline__ void gemm_mainloop_m64(const double* __restrict__ A, int64_t lda, int64_t a0, const double* __restrict__ B, int64_t ldb,
+                                                  int64_t b0, int64_t k0, int64_t k1, v4d (&acc)[2][2], double* lds) {
+  // (k1 - k0) must be a multiple of 64. A half tile has 16 MFMAs per wave and slab -- 0.2 us of pipe time -- so a one-slab prefetch leaves it
+  // waiting for memory (measured 1.1-2.2 us per slab); its 32 accumulator registers leave room for a FOUR-slab register ring instead:
+  // slab kt + 4 is requested when slab kt has moved to LDS.
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nk = (int)((k1 - k0) >> 4);
+  const int akk = (t & 7) * 2, ar = t >> 3;                    // A (k contiguous): 64 rows x 16 k = one double2 per thread
+  const double* ap = A + (a0 + ar) * lda + akk;
+  const int bj = (t & 63) * 2, bk = t >> 6;                    // B (column contiguous): 16 k x 128 columns = two double2 per thread (k, k + 8)
+  const double* bp = B + (int64_t)bk * ldb + b0 + bj;
+  double* lbs = lds + SLAB + bk * LDR + bj;
+  double* las = lds + ar * LDK + akk;
+#define RC_M64_LOAD(KK, RA, RB0, RB1)                                   \
+  RA = *reinterpret_cast<const double2*>(ap + (KK));                    \
+  RB0 = *reinterpret_cast<const double2*>(bp + (KK) * ldb);             \
+  RB1 = *reinterpret_cast<const double2*>(bp + ((KK) + 8) * ldb);
+#define RC_M64_STORE(STAGE, RA, RB0, RB1)                               \
+  las[(STAGE) * 2 * SLAB] = RA.x;                                       \
+  las[(STAGE) * 2 * SLAB + 1] = RA.y;                                   \
+  *reinterpret_cast<double2*>(lbs + (STAGE) * 2 * SLAB) = RB0;          \
+  *reinterpret_cast<double2*>(lbs + (STAGE) * 2 * SLAB + 8 * LDR) = RB1;
+  double2 ra0, ra1, ra2, ra3, rb00, rb01, rb10, rb11, rb20, rb21, rb30, rb31;
+  RC_M64_LOAD(k0, ra0, rb00, rb01)
+  RC_M64_LOAD(k0 + 16, ra1, rb10, rb11)
+  RC_M64_LOAD(k0 + 32, ra2, rb20, rb21)
+  RC_M64_LOAD(k0 + 48, ra3, rb30, rb31)
+  RC_M64_STORE(0, ra0, rb00, rb01)
+  __syncthreads();
+  // one slab: reload the register set whose slab is in LDS already (<- slab kt + 4), multiply slab kt from LDS stage U & 1, move the next slab
+  // (the N set) into the other stage
+#define RC_M64_STEP(U, RA, RB0, RB1, NA, NB0, NB1)                                                                              \
+  {                                                                                                                             \
+    const int kt = kt0 + U;                                                                                                     \
+    const double* la = lds + (U & 1) * 2 * SLAB;                                                                                \
+    const double* lb = la + SLAB;                                                                                               \
+    const int64_t kn = k0 + (int64_t)((kt + 4 < nk) ? kt + 4 : nk - 1) * 16; /* branch-free: the tail re-reads the last slab */ \
+    RC_M64_LOAD(kn, RA, RB0, RB1)                                                                                               \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                             \
+      double af[2], bf[2];                                                                                                      \
+      _Pragma("unroll") for (int x = 0; x < 2; ++x) af[x] = la[(wr + 16 * x + fr) * LDK + 4 * s + fq];                          \
+      _Pragma("unroll") for (int x = 0; x < 2; ++x) bf[x] = lb[(4 * s + fq) * LDR + wc + 16 * x + fr];                          \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                                          \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                                          \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, NEG ? 1 : 0);                     \
+    }                                                                                                                           \
+    RC_M64_STORE((U + 1) & 1, NA, NB0, NB1)                                                                                     \
+    __syncthreads();                                                                                                            \
+  }
+  for (int kt0 = 0; kt0 < nk; kt0 += 4) {
+    RC_M64_STEP(0, ra0, rb00, rb01, ra1, rb10, rb11)
+    RC_M64_STEP(1, ra1, rb10, rb11, ra2, rb20, rb21)
+    RC_M64_STEP(2, ra2, rb20, rb21, ra3, rb30, rb31)
+    RC_M64_STEP(3, ra3, rb30, rb31, ra0, rb00, rb01)
+  }
+#undef RC_M64_LOAD
+#undef RC_M64_STORE
+#undef RC_M64_STEP
+}
+
+__device__ __forceinline__ void acc_store_m64(const v4d (&acc)[2][2], double* __restrict__ Ct, int64_t ldc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32, fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ct[(int64_t)(wr + 16 * mi + 4 * r + fq) * ldc + wc + 16 * ni + fr] = acc[mi][ni][r];
+}
+
+__global__ void __launch_bounds__(512, 4) k_trtri_T_half(const double* __restrict__ Lm, const double* __restrict__ W, double* __restrict__ S,
+                                                          int64_t ld, int64_t Np, int64_t s, int pair0) {
+  __shared__ double lds[GEMM_LDS];
+  const int th = blockIdx.x, tj = blockIdx.y;                 // th: 64-row half tile of the C part; tj slow: longest k-ranges first
+  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z), rowC = colA + s;
+  if (rowC + (int64_t)th * 64 >= Np) return;
+  v4d acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = (v4d){0.0, 0.0, 0.0, 0.0};
+  gemm_mainloop_m64<false>(Lm + rowC * ld + colA, ld, (int64_t)th * 64, W + colA * ld + colA, ld, (int64_t)tj * 128, (int64_t)tj * 128, s, acc, lds);
+  acc_store_m64(acc, S + (rowC + (int64_t)th * 64) * ld + colA + (int64_t)tj * 128, ld);
+}
+
+__global__ void __launch_bounds__(512, 4) k_trtri_X_half(double* __restrict__ W, const double* __restrict__ S, int64_t ld, int64_t Np, int64_t s,
+                                                          int pair0) {
+  __shared__ double lds[GEMM_LDS];
+  const int tj = blockIdx.x, th = (int)gridDim.y - 1 - (int)blockIdx.y;     // th slow and reversed: longest k-ranges first
+  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z), rowC = colA + s;
+  if (rowC + (int64_t)th * 64 >= Np) return;
+  v4d acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // C^-1 is lower triangular down to the element (its diagonal blocks are stored with their zeros): rows [64 th, 64 th + 64) need k < 64 (th + 1)
+  gemm_mainloop_m64<true>(W + rowC * ld + rowC, ld, (int64_t)th * 64, S + rowC * ld + colA, ld, (int64_t)tj * 128, 0, (int64_t)(th + 1) * 64, acc, lds);
+  acc_store_m64(acc, W + (rowC + (int64_t)th * 64) * ld + colA + (int64_t)tj * 128, ld);
+}
+
 // T phase of `npairs` pairs starting at pair0 on level s, C-part row tiles [ti0, ti0 + nti); X phase of whole pairs.
 int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti0, int nti) {
   if (npairs <= 0 || nti <= 0) return 0;
   const int64_t st = s / 128;
   RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)nti * 128.0 * (double)s * (double)s);
+  if (ti0 == 0 && (int64_t)npairs * nti * st <= h->trtri_half_tiles) {
+    hipLaunchKernelGGL(k_trtri_T_half, dim3((unsigned)(2 * nti), (unsigned)st, (unsigned)npairs), dim3(512), 0, h->launch, h->A, h->Linv, h->S, h->Np,
+                       h->Np, s, pair0);
+    RC_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(k_trtri_T<RC_WN>, dim3((unsigned)nti, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->launch, h->A, h->Linv, h->S,
                      h->Np, h->Np, s, pair0, ti0);
   RC_HIP(hipGetLastError());
@@ -592,6 +704,12 @@ int rc_launch_trtri_X(rcgp_handle_s* h, int64_t s, int pair0, int npairs) {
   if (npairs <= 0) return 0;
   const int64_t st = s / 128;
   RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)s * (double)s * (double)s);
+  if ((int64_t)npairs * st * st <= h->trtri_half_tiles) {
+    hipLaunchKernelGGL(k_trtri_X_half, dim3((unsigned)st, (unsigned)(2 * st), (unsigned)npairs), dim3(512), 0, h->launch, h->Linv, h->S, h->Np, h->Np, s,
+                       pair0);
+    RC_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(k_trtri_X<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->S, h->Np,
                      h->Np, s, pair0);
   RC_HIP(hipGetLastError());
