@@ -2,9 +2,10 @@
 // This is GPflow's square_distance expansion (no clamp), the arithmetic behind gf.kernels.RBF.K at the reference call
 // sites gpr/kernels.py:176 and gpr/models.py:435-437 (the +noise on the diagonal is fused here).
 //
-// One workgroup = one 128x128 tile, 512 threads, 4x8 outputs per thread; the two Z panels (128 x M each) are staged in LDS
-// m-major so that a row read is a broadcast and a column read is a contiguous double2; stores are 16 B per lane, 256 B
-// contiguous per 16 lanes. Only tiles on or below the diagonal are written (the Cholesky reads the lower triangle).
+// One workgroup = one 128x128 tile, 512 threads; the two Z panels (128 x M each) are staged in LDS m-major, the dot products
+// z_i . z_j run on the matrix cores (three v_mfma_f64_16x16x4 per 16 x 16 outputs at M = 10), the exponentials on the VALU; stores
+// are 8 B per lane, 128 B contiguous per 16 lanes. Only tiles on or below the diagonal are written (the Cholesky reads the lower
+// triangle).
 #include "common.h"
 #include "rc_math.h"
 
@@ -54,7 +55,7 @@ __device__ __forceinline__ void tri_decode_g(int64_t id, int& ti, int& tj) {
 // Several outputs (covariant GP, gpf/kernels.py:93-104 and gpf/likelihoods.py:61-64): the rows/columns come in L blocks of
 // tb tiles; block pair (bi, bj) has variance FS[bi * L + bj] and, where the in-block indices agree, noise FS[L * L + bi * L + bj];
 // nr_valid / nc_valid count the valid rows of ONE block. The test points of a cross-Gram all belong to output rb.
-// 512 threads per 128x128 tile, 4x8 outputs per thread (rows ty + 32a, column pairs 2tx + 32b): <= 128 registers, so four
+// 512 threads per 128x128 tile, 32 outputs per thread (the C/D layout of 4 x 2 MFMA tiles per wave): <= 128 registers, so four
 // waves per SIMD are resident and the store phase of one wave overlaps the exp phase of the others.
 template <bool CROSS>
 __global__ void __launch_bounds__(512, 4) k_gram(double* __restrict__ out, int64_t ld, const double* __restrict__ Zr,
@@ -62,9 +63,10 @@ __global__ void __launch_bounds__(512, 4) k_gram(double* __restrict__ out, int64
                                                  const double* __restrict__ sqc, int64_t nc_valid, int M,
                                                  const double* __restrict__ FS, int L, int tb, int rb) {
   extern __shared__ double sm[];
-  double* zi = sm;                 // [M][ZST]
-  double* zj = sm + M * ZST;       // [M][ZST]
-  double* si = zj + M * ZST;       // [128]
+  const int Mp = (M + 3) & ~3;     // dimensions padded to a multiple of four (one fp64 MFMA consumes four), the padding zero
+  double* zi = sm;                 // [Mp][ZST]
+  double* zj = sm + Mp * ZST;      // [Mp][ZST]
+  double* si = zj + Mp * ZST;      // [128]
   double* sj = si + 128;           // [128]
   int ti, tj;
   if (CROSS) {
@@ -97,80 +99,79 @@ __global__ void __launch_bounds__(512, 4) k_gram(double* __restrict__ out, int64
   }
   if (t < 128) si[t] = sqr[(int64_t)ti * 128 + t];
   else if (t < 256) sj[t - 128] = sqc[(int64_t)tj * 128 + t - 128];
+  for (int e = t; e < (Mp - M) * 128; e += 512) {
+    const int m = M + e / 128, rr = e & 127;
+    zi[m * ZST + rr] = 0.0;
+    zj[m * ZST + rr] = 0.0;
+  }
   __syncthreads();
-  const int tx = t & 15, ty = t >> 4;
-  double acc[4][8];
+  // z_i . z_j on the matrix cores (the -2 Z Z^T term of the squared-distance expansion IS a 128 x 128 x M product): 8 waves as 2 x 4, a wave
+  // owns 64 x 32 = 4 x 2 MFMA tiles; A lane l = zi[k = l >> 4][row l & 15], B lane l = zj[k = l >> 4][col l & 15] -- both contiguous reads of
+  // the m-major panels; the panels are zero-padded to a multiple of four dimensions. The M fp64 FMAs per element this replaces were 10 of the
+  // ~34 VALU instructions per element at M = 10 (20 of 44 at M = 20), and the kernel is bound by VALU issue + stores.
+  const int lane = t & 63, wave = t >> 6;
+  const int wr = (wave >> 2) * 64, wc = (wave & 3) * 32;
+  const int fr = lane & 15, fq = lane >> 4;
+  v4d acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[a][c] = 0.0;
-  for (int m = 0; m < M; ++m) {
-    double ra[4];
-    double2 cb[4];
+    for (int c = 0; c < 2; ++c) acc[a][c] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int m0 = 0; m0 < Mp; m0 += 4) {
+    double af[4], bf[2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) ra[a] = zi[m * ZST + ty + 32 * a];
+    for (int x = 0; x < 4; ++x) af[x] = zi[(m0 + fq) * ZST + wr + 16 * x + fr];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) cb[b] = *reinterpret_cast<const double2*>(zj + m * ZST + 2 * tx + 32 * b);
+    for (int x = 0; x < 2; ++x) bf[x] = zj[(m0 + fq) * ZST + wc + 16 * x + fr];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        acc[a][2 * b] = fma(ra[a], cb[b].x, acc[a][2 * b]);
-        acc[a][2 * b + 1] = fma(ra[a], cb[b].y, acc[a][2 * b + 1]);
-      }
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
   }
+  // C/D layout: lane l, register r of tile (mi, ni) is element (row wr + 16 mi + 4 r + (l >> 4), column wc + 16 ni + (l & 15)): a store
+  // instruction writes four rows x 128 contiguous bytes.
+  const double sj0 = sj[wc + fr], sj1 = sj[wc + 16 + fr];
   // Interior tiles -- off the diagonal of their block pair and entirely inside the valid rows and columns: all but O(T) of the T^2/2
-  // tiles -- need none of the per-element noise / padding tests (four 64-bit compares and selects per pair of outputs, a fifth of the
-  // kernel's VALU work at M = 10, and the kernel is VALU-bound, not store-bound: 8- and 16-byte, temporal and nontemporal stores all
-  // give the same time).
+  // tiles -- need none of the per-element noise / padding tests.
   const int64_t i_lo = (int64_t)ti * 128 - ioff, j_lo = (int64_t)tj * 128 - joff;
   const bool interior = (CROSS || i_lo != j_lo || bi != bj) && i_lo + 128 <= nr_valid && j_lo + 128 <= nc_valid &&
                         (CROSS || i_lo >= j_lo + 128 || j_lo >= i_lo + 128);
   if (interior) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int row = ty + 32 * a;
-      const double sia = si[row];
-      double* dst_row = out + ((int64_t)ti * 128 + row) * ld + (int64_t)tj * 128;
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int col = 2 * tx + 32 * b;
-        __builtin_nontemporal_store(var * rc_exp(sia + sj[col] + acc[a][2 * b]), dst_row + col);
-        __builtin_nontemporal_store(var * rc_exp(sia + sj[col + 1] + acc[a][2 * b + 1]), dst_row + col + 1);
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr + 16 * mi + 4 * r + fq;
+        const double sia = si[row];
+        double* dst_row = out + ((int64_t)ti * 128 + row) * ld + (int64_t)tj * 128 + wc + fr;
+        __builtin_nontemporal_store(var * rc_exp(sia + sj0 + acc[mi][0][r]), dst_row);
+        __builtin_nontemporal_store(var * rc_exp(sia + sj1 + acc[mi][1][r]), dst_row + 16);
       }
-    }
     return;
   }
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int row = ty + 32 * a;
-    const int64_t i = (int64_t)ti * 128 + row;
-    const double sia = si[row];
+  for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int col = 2 * tx + 32 * b;
-      const int64_t j = (int64_t)tj * 128 + col;
-      double2 v;
-      v.x = var * rc_exp(sia + sj[col] + acc[a][2 * b]);
-      v.y = var * rc_exp(sia + sj[col + 1] + acc[a][2 * b + 1]);
-      const int64_t ii = i - ioff, jj = j - joff;      // in-block indices
-      if (CROSS) {
-        if (ii >= nr_valid || jj >= nc_valid) v.x = 0.0;
-        if (ii >= nr_valid || jj + 1 >= nc_valid) v.y = 0.0;
-      } else {
-        if (ii == jj) v.x += noise;
-        if (ii == jj + 1) v.y += noise;
-        if (ii >= nr_valid || jj >= nc_valid) v.x = (i == j) ? 1.0 : 0.0;
-        if (ii >= nr_valid || jj + 1 >= nc_valid) v.y = (i == j + 1) ? 1.0 : 0.0;
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr + 16 * mi + 4 * r + fq;
+      const int64_t i = (int64_t)ti * 128 + row, ii = i - ioff;            // ii, jj: in-block indices
+      const double sia = si[row];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int64_t j = (int64_t)tj * 128 + wc + 16 * ni + fr, jj = j - joff;
+        double v = var * rc_exp(sia + (ni ? sj1 : sj0) + acc[mi][ni][r]);
+        if (CROSS) {
+          if (ii >= nr_valid || jj >= nc_valid) v = 0.0;
+        } else {
+          if (ii == jj) v += noise;
+          if (ii >= nr_valid || jj >= nc_valid) v = (i == j) ? 1.0 : 0.0;
+        }
+        __builtin_nontemporal_store(v, out + i * ld + j);   // written once, read next by another kernel: keep it out of the way in L2
       }
-      double* dst = out + i * ld + j;
-      __builtin_nontemporal_store(v.x, dst);           // written once, read next by another kernel: keep it out of the way in L2
-      __builtin_nontemporal_store(v.y, dst + 1);
     }
-  }
 }
 
-static size_t gram_lds_bytes(int M) { return (size_t)(2 * M * ZST + 256) * sizeof(double); }
+static size_t gram_lds_bytes(int M) { return (size_t)(2 * ((M + 3) & ~3) * ZST + 256) * sizeof(double); }
 
 int rc_launch_gram(rcgp_handle_s* h) {
   const int64_t T = h->Np / 128;

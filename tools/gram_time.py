@@ -6,6 +6,9 @@ from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from romcomma_amd import _lib                                      # noqa: E402
+import os
+if os.environ.get('RCGP_DEV_LIB'):
+    _lib.LIB_PATH = Path(os.environ['RCGP_DEV_LIB']).resolve()
 from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
@@ -23,4 +26,4 @@ with _lib.RcGP(X, y) as gp:
         ts.append(time.perf_counter() - t0)
     t = min(ts)
     b = 8.0 * (N * (N + 1) / 2 + N * M)
-    print(f'N={N} M={M}: gram {1e3 * t:.3f} ms = {b / t / 1e9:.0f} GB/s ({b / t / 8e12:.1%} of 8 TB/s)')
+    print(f'lib={os.environ.get("RCGP_DEV_LIB", "product")} N={N} M={M}: lml {gp.lml():.13e} gram {1e3 * t:.3f} ms = {b / t / 1e9:.0f} GB/s ({b / t / 8e12:.1%} of 8 TB/s)')
