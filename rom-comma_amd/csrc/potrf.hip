@@ -576,7 +576,16 @@ static int potrf_fine(rcgp_handle_s* h) {
       if (ext) h->launch_stop = eT2;
       if ((rc = rc_launch_trsm_subst(h, P + 128 * Np, Np, Ljj, inv, below - 128, h->w + j + 256, h->w + j)) || (rc = flush_stop(h))) return rc;
       if (!ext) RC_HIP(hipEventRecord(eT2, B));
-      const int64_t c0 = j + 128, nend = (c0 + 256 < cend) ? c0 + 256 : cend;
+      // Far updates in PAIRS of steps: a panel's even steps (counted from its first column) send no far update -- their near kernel takes
+      // a third block column instead, the one that enters the near window next -- and the odd steps apply their own and the previous
+      // step's 128 columns to everything from the third block column on as ONE K = 256 product: half as many passes over the far C tiles
+      // (a K = 128 update moves a 128 KB tile in and out for 4.2 MFLOP). An even LAST step of a panel sends its far update alone.
+      const int64_t c0 = j + 128;
+      const bool odd_step = h->pair_far && ((j - (pend - NB)) / 128) % 2 == 1;
+      const bool even_step = h->pair_far && !odd_step;
+      const bool lone_far = even_step && (j + 128 == pend || j + 128 + 128 >= Np);      // no partner step in this panel
+      const int64_t nwidth = even_step ? 384 : 256;
+      const int64_t nend = (c0 + nwidth < cend) ? c0 + nwidth : cend;
       RC_HIP(hipStreamWaitEvent(B, eP, 0));
       if (eFar_prev) RC_HIP(hipStreamWaitEvent(B, eFar_prev, 0));
       if (eU1_prev && !near_waited && nend > u0_prev) { RC_HIP(hipStreamWaitEvent(B, eU1_prev, 0)); near_waited = true; }
@@ -585,14 +594,15 @@ static int potrf_fine(rcgp_handle_s* h) {
           (rc = flush_stop(h)))
         return rc;
       if (!ext) RC_HIP(hipEventRecord(eG, B));
-      if (cend > nend) {
+      if (cend > nend && (!even_step || lone_far)) {
         RC_HIP(hipStreamWaitEvent(B2, eT2, 0));
         if (eU1_prev && !far_waited && cend > u0_prev) { RC_HIP(hipStreamWaitEvent(B2, eU1_prev, 0)); far_waited = true; }
         h->launch = B2;
         if ((rc = next_event(h, &eFar))) return rc;
         if (ext) h->launch_stop = eFar;
-        if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + nend, Np, P + 128 * Np, Np, P + (nend - c0) * Np, Np, below - 128, cend - nend, 128,
-                                        j + 256, nend)) ||
+        const int64_t kk = odd_step ? 256 : 128, kcol = odd_step ? j - 128 : j;           // the L columns [kcol, kcol + kk) of the rows below
+        if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + nend, Np, h->A + (j + 256) * Np + kcol, Np, h->A + nend * Np + kcol, Np, below - 128,
+                                        cend - nend, kk, j + 256, nend)) ||
             (rc = flush_stop(h)))
           return rc;
         if (!ext) RC_HIP(hipEventRecord(eFar, B2));
