@@ -20,9 +20,6 @@
                         // ds_read2_b64, which is banked over 32 dwords in groups of 16 consecutive lanes (16 rows of one k):
                         // stride 18 was two-way conflicted there (SQ_LDS_BANK_CONFLICT 5 cycles per LDS instruction), 17 is not
 #endif
-#ifndef RC_PF
-#define RC_PF 4           // register prefetch depth (slabs) of the short-K kernels of the panel chain
-#endif
 #define LDR 144         // row stride (doubles) of a KC=false LDS slab: [16][144]
 #define SLAB 2304       // doubles per operand slab (both layouts)
 #define GEMM_LDS (4 * SLAB)
@@ -125,69 +122,6 @@ __device__ __forceinline__ void gemm_mainloop(const double* __restrict__ A, int6
     slab_store<AKC, WN>(na, ra);
     slab_store<BKC, WN>(na + SLAB, rb);
     __syncthreads();
-  }
-}
-
-// The same product for a SHORT k-range (NK slabs of 16, NK = 8 on the panel chain: K = 128) with a PF-deep register prefetch: the
-// global loads of the first PF slabs are issued before anything is waited for (by the caller, ahead of its C-tile load, or here),
-// and slab kt + PF is requested as soon as slab kt has left its registers. The rolling two-stage prefetch of gemm_mainloop exposes
-// one memory round trip per slab when there are only eight of them and the workgroup has its CU to itself -- the panel-chain
-// kernels (panel solve, K = 128 updates) spent 25-40 us per 128^2 tile that way, most of it waiting. Costs 16 PF staging
-// registers per lane, so these kernels run one workgroup per CU.
-template <bool AKC, bool BKC, int WN, bool NEG, int NK, int PF>
-__device__ __forceinline__ void gemm_mainloop_pre(const double* __restrict__ A, int64_t lda, int64_t a0, const double* __restrict__ B,
-                                                  int64_t ldb, int64_t b0, int64_t k0, v4d (&acc)[4][Geo<WN>::NI], double* lds,
-                                                  RegsN<WN> (&ra)[PF], RegsN<WN> (&rb)[PF], bool loaded) {
-  constexpr int NI = Geo<WN>::NI;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = (wave / WN) * 64, wc = (wave % WN) * (16 * NI);
-  const int fr = lane & 15, fq = lane >> 4;
-  if (!loaded) {
-#pragma unroll
-    for (int kt = 0; kt < PF; ++kt) {
-      slab_load<AKC, WN>(A, lda, a0, k0 + 16 * kt, ra[kt]);
-      slab_load<BKC, WN>(B, ldb, b0, k0 + 16 * kt, rb[kt]);
-    }
-  }
-  slab_store<AKC, WN>(lds, ra[0]);
-  slab_store<BKC, WN>(lds + SLAB, rb[0]);
-  __syncthreads();
-#pragma unroll
-  for (int kt = 0; kt < NK; ++kt) {
-    const double* la = lds + (kt & 1) * 2 * SLAB;
-    const double* lb = la + SLAB;
-    if (kt + PF < NK) {                                     // slot kt % PF went to LDS one iteration ago
-      slab_load<AKC, WN>(A, lda, a0, k0 + 16 * (kt + PF), ra[kt % PF]);
-      slab_load<BKC, WN>(B, ldb, b0, k0 + 16 * (kt + PF), rb[kt % PF]);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      double af[4], bf[NI];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) af[x] = frag_read<AKC>(la, wr + 16 * x + fr, 4 * s + fq);
-#pragma unroll
-      for (int x = 0; x < NI; ++x) bf[x] = frag_read<BKC>(lb, wc + 16 * x + fr, 4 * s + fq);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, NEG ? 1 : 0);
-    }
-    if (kt + 1 < NK) {
-      double* na = lds + ((kt + 1) & 1) * 2 * SLAB;
-      slab_store<AKC, WN>(na, ra[(kt + 1) % PF]);
-      slab_store<BKC, WN>(na + SLAB, rb[(kt + 1) % PF]);
-    }
-    __syncthreads();
-  }
-}
-
-template <bool AKC, bool BKC, int WN, int PF>
-__device__ __forceinline__ void slabs_load_first(const double* __restrict__ A, int64_t lda, int64_t a0, const double* __restrict__ B, int64_t ldb,
-                                                 int64_t b0, int64_t k0, RegsN<WN> (&ra)[PF], RegsN<WN> (&rb)[PF]) {
-#pragma unroll
-  for (int kt = 0; kt < PF; ++kt) {
-    slab_load<AKC, WN>(A, lda, a0, k0 + 16 * kt, ra[kt]);
-    slab_load<BKC, WN>(B, ldb, b0, k0 + 16 * kt, rb[kt]);
   }
 }
 
@@ -323,34 +257,95 @@ __global__ void RC_BOUNDS(WN) k_gemm_nt_sub(double* __restrict__ C, int64_t ldc,
   if (STAGED & 2) acc_store_staged<WN>(acc, Ct, ldc, lds); else acc_store<WN>(acc, Ct, ldc);
 }
 
-// K = 128 (the panel chain's column updates): every operand slab and the C tile requested before anything is waited for
-template <int WN>
-__global__ void __launch_bounds__(128 * WN) k_gemm_nt_sub_k128(double* __restrict__ C, int64_t ldc, const double* __restrict__ A, int64_t lda,
-                                                              const double* __restrict__ B, int64_t ldb, int64_t row0, int64_t col0) {
-  __shared__ double lds[GEMM_LDS];
-  const int tj = blockIdx.x, ti = blockIdx.y;
-  if (col0 + (int64_t)tj * 128 > row0 + (int64_t)ti * 128) return;
-  RegsN<WN> ra[RC_PF], rb[RC_PF];
-  slabs_load_first<true, true, WN, RC_PF>(A, lda, (int64_t)ti * 128, B, ldb, (int64_t)tj * 128, 0, ra, rb);
-  v4d acc[4][Geo<WN>::NI];
-  double* Ct = C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128;
-  acc_load_staged<WN>(acc, Ct, ldc, lds);
-  gemm_mainloop_pre<true, true, WN, true, 8, RC_PF>(A, lda, (int64_t)ti * 128, B, ldb, (int64_t)tj * 128, 0, acc, lds, ra, rb, true);
-  acc_store_staged<WN>(acc, Ct, ldc, lds);
+// The same update on 64 x 128 HALF tiles for short k (kk = 128 or 256: the near / far updates of the panel chain). A 128^2 tile with K = 128 is
+// 13.7 us of MFMA time per CU behind a C tile and eight operand slabs that have to arrive first; with two workgroups per CU that took 23-27 us
+// per tile. Half tiles: 32 accumulator registers, the C half tile and the first four operand slabs requested up front (register ring as in
+// gemm_mainloop_m64, both operands k-contiguous), two workgroups per CU at <= 128 registers.
+__global__ void __launch_bounds__(512, 4) k_gemm_nt_sub_h64(double* __restrict__ C, int64_t ldc, const double* __restrict__ A, int64_t lda,
+                                                             const double* __restrict__ B, int64_t ldb, int kk, int64_t row0, int64_t col0) {
+  __shared__ double lds[2 * 3 * 64 * LDK];                      // two stages of A [64][LDK] + B [128][LDK]
+  const int tj = blockIdx.x, th = blockIdx.y;
+  if (col0 + (int64_t)tj * 128 > row0 + (int64_t)th * 64) return;    // (row0, col0 multiples of 128: a half tile is below the diagonal with its tile)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nk = kk >> 4;
+  const int skk = (t & 7) * 2, sr = t >> 3;                     // slab element of this thread: row sr (A; B rows sr and sr + 64), k pair skk
+  const double* ap = A + ((int64_t)th * 64 + sr) * lda + skk;
+  const double* bp = B + ((int64_t)tj * 128 + sr) * ldb + skk;
+  constexpr int STAGE = 3 * 64 * LDK;
+  double* las = lds + sr * LDK + skk;
+  double* lbs = lds + 64 * LDK + sr * LDK + skk;
+#define RC_H64_LOAD(KK, RA, RB0, RB1)                                  \
+  RA = *reinterpret_cast<const double2*>(ap + (KK));                   \
+  RB0 = *reinterpret_cast<const double2*>(bp + (KK));                  \
+  RB1 = *reinterpret_cast<const double2*>(bp + 64 * ldb + (KK));
+#define RC_H64_STORE(ST, RA, RB0, RB1)                                 \
+  las[(ST) * STAGE] = RA.x;  las[(ST) * STAGE + 1] = RA.y;             \
+  lbs[(ST) * STAGE] = RB0.x; lbs[(ST) * STAGE + 1] = RB0.y;            \
+  lbs[(ST) * STAGE + 64 * LDK] = RB1.x; lbs[(ST) * STAGE + 64 * LDK + 1] = RB1.y;
+  double2 ra0, ra1, ra2, ra3, rb00, rb01, rb10, rb11, rb20, rb21, rb30, rb31;
+  RC_H64_LOAD(0, ra0, rb00, rb01)
+  RC_H64_LOAD(16, ra1, rb10, rb11)
+  RC_H64_LOAD(32, ra2, rb20, rb21)
+  RC_H64_LOAD(48, ra3, rb30, rb31)
+  v4d acc[2][2];
+  double* Ct = C + ((int64_t)th * 64 + wr + fq) * ldc + (int64_t)tj * 128 + wc + fr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mi][ni][r] = Ct[(int64_t)(16 * mi + 4 * r) * ldc + 16 * ni];
+  RC_H64_STORE(0, ra0, rb00, rb01)
+  __syncthreads();
+#define RC_H64_STEP(U, RA, RB0, RB1, NA, NB0, NB1)                                                                              \
+  {                                                                                                                             \
+    const int kt = kt0 + U;                                                                                                     \
+    const double* la = lds + (U & 1) * STAGE;                                                                                   \
+    const double* lb = la + 64 * LDK;                                                                                           \
+    const int kn = ((kt + 4 < nk) ? kt + 4 : nk - 1) * 16;                   /* branch-free: the tail re-reads the last slab */ \
+    RC_H64_LOAD(kn, RA, RB0, RB1)                                                                                               \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                             \
+      double af[2], bf[2];                                                                                                      \
+      _Pragma("unroll") for (int x = 0; x < 2; ++x) af[x] = la[(wr + 16 * x + fr) * LDK + 4 * s + fq];                          \
+      _Pragma("unroll") for (int x = 0; x < 2; ++x) bf[x] = lb[(wc + 16 * x + fr) * LDK + 4 * s + fq];                          \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                                          \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                                          \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 1);                               \
+    }                                                                                                                           \
+    RC_H64_STORE((U + 1) & 1, NA, NB0, NB1)                                                                                     \
+    __syncthreads();                                                                                                            \
+  }
+  for (int kt0 = 0; kt0 < nk; kt0 += 4) {
+    RC_H64_STEP(0, ra0, rb00, rb01, ra1, rb10, rb11)
+    RC_H64_STEP(1, ra1, rb10, rb11, ra2, rb20, rb21)
+    RC_H64_STEP(2, ra2, rb20, rb21, ra3, rb30, rb31)
+    RC_H64_STEP(3, ra3, rb30, rb31, ra0, rb00, rb01)
+  }
+#undef RC_H64_LOAD
+#undef RC_H64_STORE
+#undef RC_H64_STEP
+  int64_t ldo = ldc;                                            // opaque copy: the sixteen store addresses are formed here, not kept from the loads
+  asm volatile("" : "+s"(ldo));
+  double* Co = C + ((int64_t)th * 64 + wr + fq) * ldo + (int64_t)tj * 128 + wc + fr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Co[(int64_t)(16 * mi + 4 * r) * ldo + 16 * ni] = acc[mi][ni][r];
 }
 
 int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0) {
   if (m <= 0 || n <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)m * (double)n * (double)kk, true);
-  const dim3 grid((unsigned)(n / 128), (unsigned)(m / 128)), block(128 * RC_WN);
-  // the up-front-prefetch variant runs one workgroup per CU: it wins while the launch is one round of tiles (latency-bound: near / far
-  // updates of the chain at N <= ~8000 and in the tail of larger systems: 46 -> 28 us per kernel) and loses when tiles queue for CUs
-  // (N = 28672 factorisation 138.5 -> 140.9 ms with it everywhere)
-  if (kk == 128 && (m / 128) * (n / 128) <= 512 && m <= 96 * 128) {
-    RC_LAUNCH((k_gemm_nt_sub_k128<RC_WN>), grid, block, 0, C, ldc, A, lda, B, ldb, row0, col0);
+  if (kk <= 256 && kk % 64 == 0) {     // the panel chain's near / far updates (K = 128, 256): half tiles, everything requested up front
+    RC_LAUNCH(k_gemm_nt_sub_h64, dim3((unsigned)(n / 128), (unsigned)(m / 64)), dim3(512), 0, C, ldc, A, lda, B, ldb, (int)kk, row0, col0);
   } else {
-    RC_LAUNCH((k_gemm_nt_sub<RC_WN, 3>), grid, block, 0, C, ldc, A, lda, B, ldb, (int)kk, row0, col0);
+    RC_LAUNCH((k_gemm_nt_sub<RC_WN, 3>), dim3((unsigned)(n / 128), (unsigned)(m / 128)), dim3(128 * RC_WN), 0, C, ldc, A, lda, B, ldb, (int)kk, row0,
+              col0);
   }
   RC_HIP(hipGetLastError());
   return 0;

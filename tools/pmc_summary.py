@@ -12,7 +12,7 @@ import os
 import json
 import sys
 
-GEMM = ('k_syrk_lower', 'k_gemm_nt_sub', 'k_gemm_nt_sub_k128', 'k_trsm_subst', 'k_prep2', 'k_trtri_T', 'k_trtri_X', 'k_grad', 'k_predict_var')
+GEMM = ('k_syrk_lower', 'k_gemm_nt_sub', 'k_gemm_nt_sub_h64', 'k_trsm_subst', 'k_prep2', 'k_trtri_T', 'k_trtri_X', 'k_grad', 'k_predict_var')
 
 
 def rows(folder, name):
