@@ -17,8 +17,11 @@
 #ifndef RC_TRTRI_HALF_TILES
 #define RC_TRTRI_HALF_TILES 1024
 #endif
-#ifndef RC_PAIR_FAR
-#define RC_PAIR_FAR true
+#ifndef RC_TAIL_BLOCKS
+#define RC_TAIL_BLOCKS 64
+#endif
+#ifndef RC_FAR_GROUP
+#define RC_FAR_GROUP 2
 #endif
 #define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
 
@@ -56,7 +59,8 @@ struct rcgp_handle_s {
   bool fine_chain = true;            // RCGP_FINE: 0 = one stream per panel chain (D, T, G in order), one-panel look-ahead
   int64_t nb_outer = RC_NB_OUTER;    // RCGP_NB: outer panel width
   int chain_depth = 2;               // RCGP_DEPTH >= 1: column panels updated by their own kernels ahead of the bulk trailing update
-  bool pair_far = RC_PAIR_FAR;       // far updates of the panel chain in pairs of steps (K = 256), potrf.hip
+  int tail_blocks = RC_TAIL_BLOCKS;   // the last this-many block columns of the factorisation form one fine-grained panel (potrf.hip)
+  int far_group = RC_FAR_GROUP;      // far updates of the panel chain in groups of this many steps (K = 128 x group), potrf.hip
   int chain_ext = 4;                 // RCGP_EXT >= 1: 128-blocks past its own panel that a chain step keeps up to date
   int64_t trtri_half_tiles = RC_TRTRI_HALF_TILES;   // L^-1 launches of at most this many 128^2 tiles run on 64 x 128 half tiles (gemm.hip)
   int64_t N = 0, Np = 0;       // training rows per output; rows of the whole system, L * Nb

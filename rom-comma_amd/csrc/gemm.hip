@@ -341,7 +341,7 @@ int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0) {
   if (m <= 0 || n <= 0) return 0;
   RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)m * (double)n * (double)kk, true);
-  if (kk <= 256 && kk % 64 == 0) {     // the panel chain's near / far updates (K = 128, 256): half tiles, everything requested up front
+  if (kk <= 512 && kk % 64 == 0) {     // the panel chain's near / far updates (K = 128 ... 512): half tiles, everything requested up front
     RC_LAUNCH(k_gemm_nt_sub_h64, dim3((unsigned)(n / 128), (unsigned)(m / 64)), dim3(512), 0, C, ldc, A, lda, B, ldb, (int)kk, row0, col0);
   } else {
     RC_LAUNCH((k_gemm_nt_sub<RC_WN, 3>), dim3((unsigned)(n / 128), (unsigned)(m / 128)), dim3(128 * RC_WN), 0, C, ldc, A, lda, B, ldb, (int)kk, row0,

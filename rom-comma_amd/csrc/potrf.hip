@@ -541,6 +541,18 @@ static int potrf_fine(rcgp_handle_s* h) {
   hipEvent_t eG_prev = nullptr, eU1_prev = nullptr, eU2_prev = nullptr, eFar_prev = nullptr;
   bool near_waited = false, far_waited = false;                  // this panel's wait for the previous panel's window piece
   int64_t u0_prev = 0;                                           // first column of that piece
+  // The TAIL: the last `tail_blocks` block columns (rounded to whole panels) are ONE panel -- no K = NB updates any more, every update
+  // fine-grained. Down there a panel's bulk update is a few hundred tiles, and it still stops the chain for its whole duration (the
+  // chain's whole-CU kernel finds no empty CU beside it), while the K = 128 / 256 column work of a 40-block column hides behind the
+  // chain's 73 us steps. The tail's updates reach to the last column, so they wait for EVERY outstanding K = NB update first.
+  int64_t tail0 = Np;
+  if (h->tail_blocks > 0) {
+    const int64_t t = Np - 128 * (int64_t)h->tail_blocks;
+    tail0 = (t <= 0) ? 0 : ((t + NB - 1) / NB) * NB;
+    if (tail0 >= Np) tail0 = Np;
+  }
+  hipEvent_t eU1_all = nullptr, eU2_last = nullptr;              // every window piece / every bulk update launched so far
+  bool near_all_waited = false, far_all_waited = false;
   const bool ext = !h->profiling;                                // (a profiling bracket records its own events around a launch)
   for (int64_t j = 0; j < Np; j += 128) {
     const int64_t below = Np - (j + 128);
@@ -550,9 +562,11 @@ static int potrf_fine(rcgp_handle_s* h) {
     if (ext) h->launch_stop = eD;
     if ((rc = rc_launch_diag(h, j)) || (rc = flush_stop(h))) return rc;
     if (below <= 0) break;
-    const int64_t pend = (j / NB + 1) * NB;                      // end of the panel block j belongs to
+    const bool in_tail = (j >= tail0);
+    const int64_t p0 = in_tail ? tail0 : (j / NB) * NB;          // the panel block j belongs to: [p0, pend)
+    const int64_t pend = in_tail ? Np : p0 + NB;
     const int64_t cend = (pend + EXT < Np) ? pend + EXT : Np;    // G(j) covers the block columns [j + 128, cend)
-    const bool first_of_panel = (j > 0 && j % NB == 0);
+    const bool first_of_panel = (j > 0 && j == p0);
     double* P = h->A + (j + 128) * Np + j;                       // rows below the diagonal block, 128 columns
     const double* Ljj = h->A + j * Np + j;
     const double* inv = h->invdiag + (j / 128) * 128 * 128;
@@ -576,31 +590,41 @@ static int potrf_fine(rcgp_handle_s* h) {
       if (ext) h->launch_stop = eT2;
       if ((rc = rc_launch_trsm_subst(h, P + 128 * Np, Np, Ljj, inv, below - 128, h->w + j + 256, h->w + j)) || (rc = flush_stop(h))) return rc;
       if (!ext) RC_HIP(hipEventRecord(eT2, B));
-      // Far updates in PAIRS of steps: a panel's even steps (counted from its first column) send no far update -- their near kernel takes
-      // a third block column instead, the one that enters the near window next -- and the odd steps apply their own and the previous
-      // step's 128 columns to everything from the third block column on as ONE K = 256 product: half as many passes over the far C tiles
-      // (a K = 128 update moves a 128 KB tile in and out for 4.2 MFLOP). An even LAST step of a panel sends its far update alone.
+      // Far updates in GROUPS of G steps (G = far_group, 2): within a panel, step r of a group (r = 0 .. G-1, counted from the panel's first
+      // column) sends no far update unless it is the group's last -- its near kernel takes G + 1 - r block columns instead of two, the ones that
+      // enter the near window before the group is complete -- and the last step applies the whole group's 128 G columns to everything from the
+      // third block column on as ONE K = 128 G product: 1/G as many passes over the far C tiles (a K = 128 update moves a 128 KB tile in and out
+      // for 4.2 MFLOP). A panel that ends inside a group sends the incomplete group with its last step.
       const int64_t c0 = j + 128;
-      const bool odd_step = h->pair_far && ((j - (pend - NB)) / 128) % 2 == 1;
-      const bool even_step = h->pair_far && !odd_step;
-      const bool lone_far = even_step && (j + 128 == pend || j + 128 + 128 >= Np);      // no partner step in this panel
-      const int64_t nwidth = even_step ? 384 : 256;
+      const int G = h->far_group, r = (int)(((j - p0) / 128) % G);
+      const bool group_end = (r == G - 1), panel_end = (j + 128 == pend);
+      const int64_t nwidth = 128 * (int64_t)(G + 1 - r);
       const int64_t nend = (c0 + nwidth < cend) ? c0 + nwidth : cend;
       RC_HIP(hipStreamWaitEvent(B, eP, 0));
       if (eFar_prev) RC_HIP(hipStreamWaitEvent(B, eFar_prev, 0));
       if (eU1_prev && !near_waited && nend > u0_prev) { RC_HIP(hipStreamWaitEvent(B, eU1_prev, 0)); near_waited = true; }
+      if (in_tail && !near_all_waited && nend > u0_prev + NB) {    // past the first window piece's columns: everything else that is outstanding
+        if (eU1_all) RC_HIP(hipStreamWaitEvent(B, eU1_all, 0));
+        if (eU2_last) RC_HIP(hipStreamWaitEvent(B, eU2_last, 0));
+        near_all_waited = true;
+      }
       if (ext) h->launch_stop = eG;
       if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + c0, Np, P + 128 * Np, Np, P, Np, below - 128, nend - c0, 128, j + 256, c0)) ||
           (rc = flush_stop(h)))
         return rc;
       if (!ext) RC_HIP(hipEventRecord(eG, B));
-      if (cend > nend && (!even_step || lone_far)) {
+      if (cend > nend && (group_end || panel_end)) {
         RC_HIP(hipStreamWaitEvent(B2, eT2, 0));
         if (eU1_prev && !far_waited && cend > u0_prev) { RC_HIP(hipStreamWaitEvent(B2, eU1_prev, 0)); far_waited = true; }
+        if (in_tail && !far_all_waited) {
+          if (eU1_all) RC_HIP(hipStreamWaitEvent(B2, eU1_all, 0));
+          if (eU2_last) RC_HIP(hipStreamWaitEvent(B2, eU2_last, 0));
+          far_all_waited = true;
+        }
         h->launch = B2;
         if ((rc = next_event(h, &eFar))) return rc;
         if (ext) h->launch_stop = eFar;
-        const int64_t kk = odd_step ? 256 : 128, kcol = odd_step ? j - 128 : j;           // the L columns [kcol, kcol + kk) of the rows below
+        const int64_t kk = 128 * (int64_t)(r + 1), kcol = j - 128 * (int64_t)r;            // the L columns [kcol, kcol + kk) of the rows below
         if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + nend, Np, h->A + (j + 256) * Np + kcol, Np, h->A + nend * Np + kcol, Np, below - 128,
                                         cend - nend, kk, j + 256, nend)) ||
             (rc = flush_stop(h)))
@@ -626,7 +650,7 @@ static int potrf_fine(rcgp_handle_s* h) {
       // chain reaches it with depth 1, `depth` panels before with a deeper window: the chain may run that far ahead of the bulk.
       eU1_prev = nullptr;
       const int depth = h->chain_depth;
-      const double* Lp0 = h->A + (pend - NB);                     // column offset of the finished panel
+      const double* Lp0 = h->A + p0;                              // column offset of the finished panel
       hipEvent_t eR_new = nullptr;
       for (int q = 0; q <= depth; ++q) {
         const int64_t u0 = pend + EXT + (int64_t)q * NB;
@@ -658,6 +682,11 @@ static int potrf_fine(rcgp_handle_s* h) {
         }
       }
       eU2_prev = eR_new;
+      if (eR_new) eU2_last = eR_new;
+      if (pend == tail0 && pend + EXT < Np) {                     // the tail starts here: one event behind every window piece
+        if ((rc = next_event(h, &eU1_all))) return rc;
+        RC_HIP(hipEventRecord(eU1_all, U1));
+      }
     }
   }
   h->launch = h->stream;
@@ -669,7 +698,7 @@ static int potrf_fine(rcgp_handle_s* h) {
   RC_HIP(hipStreamWaitEvent(h->stream, eC, 0));
   RC_HIP(hipStreamWaitEvent(h->stream, eB, 0));
   RC_HIP(hipStreamWaitEvent(h->stream, eB2, 0));
-  if (eU2_prev) RC_HIP(hipStreamWaitEvent(h->stream, eU2_prev, 0));
+  if (eU2_last) RC_HIP(hipStreamWaitEvent(h->stream, eU2_last, 0));
   return 0;
 }
 

@@ -32,6 +32,10 @@ if steps:
     steps_sorted = sorted(steps)
     print(f'diag start-to-start: n={len(steps)} median {steps_sorted[len(steps) // 2]:.1f} us  mean {sum(steps) / len(steps):.1f}  '
           f'min {steps_sorted[0]:.1f} max {steps_sorted[-1]:.1f}')
+if steps:
+    print('steps in order (us), eight per line = one panel at NB = 1024:')
+    for i in range(0, len(steps), 8):
+        print('  ' + ' '.join(f'{x:7.1f}' for x in steps[i:i + 8]) + f'   | sum {sum(steps[i:i + 8]):8.1f}')
 print('--- first kernels of the pass (start us, dur us, queue, name)')
 for r in last[:nshow]:
     print(f"{(r['s'] - t0) / 1e3:10.1f} {(r['e'] - r['s']) / 1e3:8.1f}  q{r.get('Queue_Id', '?'):>3s}  {r['n']}")
