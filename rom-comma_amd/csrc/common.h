@@ -23,6 +23,12 @@
 #ifndef RC_FAR_GROUP
 #define RC_FAR_GROUP 2
 #endif
+#ifndef RC_FAR_SPLIT_MIN
+#define RC_FAR_SPLIT_MIN 40
+#endif
+#ifndef RC_LEAN_BLOCKS
+#define RC_LEAN_BLOCKS 40
+#endif
 #define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -60,6 +66,8 @@ struct rcgp_handle_s {
   int64_t nb_outer = RC_NB_OUTER;    // RCGP_NB: outer panel width
   int chain_depth = 2;               // RCGP_DEPTH >= 1: column panels updated by their own kernels ahead of the bulk trailing update
   int tail_blocks = RC_TAIL_BLOCKS;   // the last this-many block columns of the factorisation form one fine-grained panel (potrf.hip)
+  int lean_blocks = RC_LEAN_BLOCKS;   // chain steps with at most this many blocks below them carry ONE completion signal (potrf.hip)
+  int far_split_min = RC_FAR_SPLIT_MIN;   // columns taller than this many blocks: a far update as two launches (potrf.hip)
   int far_group = RC_FAR_GROUP;      // far updates of the panel chain in groups of this many steps (K = 128 x group), potrf.hip
   int chain_ext = 4;                 // RCGP_EXT >= 1: 128-blocks past its own panel that a chain step keeps up to date
   int64_t trtri_half_tiles = RC_TRTRI_HALF_TILES;   // L^-1 launches of at most this many 128^2 tiles run on 64 x 128 half tiles (gemm.hip)

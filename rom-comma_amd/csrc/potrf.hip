@@ -539,6 +539,8 @@ static int potrf_fine(rcgp_handle_s* h) {
   RC_HIP(hipStreamWaitEvent(B, e0, 0));
   RC_HIP(hipStreamWaitEvent(B2, e0, 0));
   hipEvent_t eG_prev = nullptr, eU1_prev = nullptr, eU2_prev = nullptr, eFar_prev = nullptr;
+  hipEvent_t eFar_last = nullptr, eFarB = nullptr;              // the last far launch of all; the last far B no far A has followed yet
+  int64_t farB_lo = 0;                                           // ... and its first column
   bool near_waited = false, far_waited = false;                  // this panel's wait for the previous panel's window piece
   int64_t u0_prev = 0;                                           // first column of that piece
   // The TAIL: the last `tail_blocks` block columns (rounded to whole panels) are ONE panel -- no K = NB updates any more, every update
@@ -558,8 +560,14 @@ static int potrf_fine(rcgp_handle_s* h) {
     const int64_t below = Np - (j + 128);
     hipEvent_t eD = nullptr, eP, eG;
     if (below > 0 && (rc = next_event(h, &eD))) return rc;
+    // LEAN steps (the column below is at most lean_blocks blocks tall: the latency-bound part of a factorisation): the diagonal kernel carries
+    // no completion signal -- the tile solve follows it in stream order without the microseconds a signal costs its successor -- and the
+    // column work waits for the tile solve's signal alone. It then starts ~10 us later, which a short column can afford and a tall one
+    // cannot (there the panel solve is on the critical path: all steps lean costs 1 % at C2). N = 4096 2.39 -> 2.31 ms, N = 8192 6.70 -> 6.58.
+    // Dropping the panel solve's signal as well (far update behind the near one) was slower: the far update then runs beside the next tile solve.
+    const bool lean = ext && below > 0 && below <= 128 * (int64_t)h->lean_blocks;
     h->launch = C;
-    if (ext) h->launch_stop = eD;
+    if (ext && !lean) h->launch_stop = eD;
     if ((rc = rc_launch_diag(h, j)) || (rc = flush_stop(h))) return rc;
     if (below <= 0) break;
     const bool in_tail = (j >= tail0);
@@ -572,7 +580,7 @@ static int potrf_fine(rcgp_handle_s* h) {
     const double* inv = h->invdiag + (j / 128) * 128 * 128;
     if ((rc = next_event(h, &eP)) || (rc = next_event(h, &eG))) return rc;
     if (!ext) RC_HIP(hipEventRecord(eD, C));
-    RC_HIP(hipStreamWaitEvent(B, eD, 0));
+    if (!lean) RC_HIP(hipStreamWaitEvent(B, eD, 0));
     if (eG_prev) RC_HIP(hipStreamWaitEvent(C, eG_prev, 0));
     if (first_of_panel && eU1_prev && h->chain_ext < 2) RC_HIP(hipStreamWaitEvent(C, eU1_prev, 0));   // P touches column j + 128 >= u0
     if (ext) h->launch_stop = eP;                                 // (taken by the tile solve: the column work needs the solved tile only)
@@ -587,6 +595,7 @@ static int potrf_fine(rcgp_handle_s* h) {
       // columns of the previous panel's window piece, wait for that piece: the chain does not stop at a panel boundary.
       hipEvent_t eT2, eFar;
       if ((rc = next_event(h, &eT2))) return rc;
+      if (lean) RC_HIP(hipStreamWaitEvent(B, eP, 0));
       if (ext) h->launch_stop = eT2;
       if ((rc = rc_launch_trsm_subst(h, P + 128 * Np, Np, Ljj, inv, below - 128, h->w + j + 256, h->w + j)) || (rc = flush_stop(h))) return rc;
       if (!ext) RC_HIP(hipEventRecord(eT2, B));
@@ -600,8 +609,9 @@ static int potrf_fine(rcgp_handle_s* h) {
       const bool group_end = (r == G - 1), panel_end = (j + 128 == pend);
       const int64_t nwidth = 128 * (int64_t)(G + 1 - r);
       const int64_t nend = (c0 + nwidth < cend) ? c0 + nwidth : cend;
-      RC_HIP(hipStreamWaitEvent(B, eP, 0));
+      if (!lean) RC_HIP(hipStreamWaitEvent(B, eP, 0));
       if (eFar_prev) RC_HIP(hipStreamWaitEvent(B, eFar_prev, 0));
+      if (eFarB && nend > farB_lo) RC_HIP(hipStreamWaitEvent(B, eFarB, 0));      // (never in the regular pattern: a near window inside the last far B)
       if (eU1_prev && !near_waited && nend > u0_prev) { RC_HIP(hipStreamWaitEvent(B, eU1_prev, 0)); near_waited = true; }
       if (in_tail && !near_all_waited && nend > u0_prev + NB) {    // past the first window piece's columns: everything else that is outstanding
         if (eU1_all) RC_HIP(hipStreamWaitEvent(B, eU1_all, 0));
@@ -622,19 +632,36 @@ static int potrf_fine(rcgp_handle_s* h) {
           far_all_waited = true;
         }
         h->launch = B2;
+        // Two launches: far A = the G block columns that the NEXT group's near windows write -- the only part a near update has to wait for
+        // (two kernels must not read-modify-write one tile at a time) -- then far B = everything beyond, which nothing touches before the
+        // next group's far A (behind it in stream order). As one kernel the whole far update (14 GFLOP, 280 us at the first steps of
+        // N = 8192) sat between this step's panel solve and the next step's near update.
+        const int64_t kk = 128 * (int64_t)(r + 1), kcol = j - 128 * (int64_t)r;            // the L columns [kcol, kcol + kk) of the rows below
+        const int64_t aend = (below > 128 * (int64_t)h->far_split_min && nend + 128 * (int64_t)G < cend) ? nend + 128 * (int64_t)G : cend;
         if ((rc = next_event(h, &eFar))) return rc;
         if (ext) h->launch_stop = eFar;
-        const int64_t kk = 128 * (int64_t)(r + 1), kcol = j - 128 * (int64_t)r;            // the L columns [kcol, kcol + kk) of the rows below
         if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + nend, Np, h->A + (j + 256) * Np + kcol, Np, h->A + nend * Np + kcol, Np, below - 128,
-                                        cend - nend, kk, j + 256, nend)) ||
+                                        aend - nend, kk, j + 256, nend)) ||
             (rc = flush_stop(h)))
           return rc;
         if (!ext) RC_HIP(hipEventRecord(eFar, B2));
-        eFar_prev = eFar;
+        eFar_prev = eFar_last = eFar;
+        eFarB = nullptr;                                          // (an earlier far B is behind this far A in stream order)
+        if (cend > aend) {
+          if ((rc = next_event(h, &eFarB))) return rc;
+          if (ext) h->launch_stop = eFarB;
+          if ((rc = rc_launch_gemm_nt_sub(h, h->A + (j + 256) * Np + aend, Np, h->A + (j + 256) * Np + kcol, Np, h->A + aend * Np + kcol, Np, below - 128,
+                                          cend - aend, kk, j + 256, aend)) ||
+              (rc = flush_stop(h)))
+            return rc;
+          if (!ext) RC_HIP(hipEventRecord(eFarB, B2));
+          eFar_last = eFarB;
+          farB_lo = aend;
+        }
       }
       if (j + 128 == pend) {                                      // the outer updates need both halves
         if ((rc = next_event(h, &ePanel))) return rc;
-        if (eFar_prev) RC_HIP(hipStreamWaitEvent(B, eFar_prev, 0));
+        if (eFar_last) RC_HIP(hipStreamWaitEvent(B, eFar_last, 0));
         RC_HIP(hipEventRecord(ePanel, B));
       }
     } else {

@@ -10,6 +10,9 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from romcomma_amd import _lib                                      # noqa: E402
+import os
+if os.environ.get('RCGP_DEV_LIB'):
+    _lib.LIB_PATH = Path(os.environ['RCGP_DEV_LIB']).resolve()
 from romcomma_amd.user.sample import bench_hyper, synthetic_fold   # noqa: E402
 
 N, M = int(sys.argv[1]), int(sys.argv[2])
