@@ -81,3 +81,35 @@ def test_standard_errors_are_of_the_size_of_the_actual_errors(gpu, tmp_path):
             assert np.all(np.abs(S - want[name]) <= 3.0 * T + 5e-4), (name, S - want[name], T)
     finally:
         gp.close()
+
+
+def test_cross_output_indices_against_their_analytic_values(gpu, tmp_path):
+    """The off-diagonal entries S_lj(S) = Cov(E[f_l | x_S], E[f_j | x_S]) / sqrt(Var f_l Var f_j) that the reference fills for independent GPs
+    too (gsa/calibrators.py:79; rows l.0 != l.1 of S.csv) -- for the reference's Ishigami 'standard' (A = 7, B = 0.1) and 'sin' (A = B = 0:
+    f = sin x1) outputs (user/functions.py:144-146) they are known in closed form: E[f_sin | x_S] = sin x1 if input 0 is in S, else 0, so
+    S_01(S) = (1 + B pi^4 / 5) / 2 / sqrt(Var f_standard / 2) = 0.5603 for every S that contains input 0 and 0 otherwise."""
+    from romcomma_amd.data.storage import Fold, Repository
+    from romcomma_amd.user import run
+    M, N = 3, 2048
+    rng = np.random.default_rng(5)
+    u = (np.stack([rng.permutation(N) for _ in range(M)], axis=1) + rng.random((N, M))) / N
+    Y = np.stack([kf.ishigami(u), kf.ishigami(u, A=0.0, B=0.0)], axis=1)
+    Y = (Y - Y.mean(axis=0)) / Y.std(axis=0) + 0.02 * rng.standard_normal(Y.shape)     # a little noise keeps the fit of the one-input output well conditioned
+    columns = pd.MultiIndex.from_tuples([('X', f'X.{m}') for m in range(M)] + [('Y', 'Y.0'), ('Y', 'Y.1')])
+    repo = Repository.from_df(tmp_path / 'repo', pd.DataFrame(np.concatenate([u, Y], axis=1), columns=columns)).into_K_folds(4, seed=2)
+    run.gpr('gpr', repo, is_read=False, is_covariant=False, is_isotropic=None)
+    run.gsa('gpr', repo, is_covariant=False, is_isotropic=False)
+    B = 0.1
+    cross = 0.5 * (1.0 + B * np.pi ** 4 / 5.0) / np.sqrt(sum(kf.ishigami_variances().values()) * 0.5)
+    assert cross == pytest.approx(0.5603, abs=1e-4)
+    want = {'first_order': np.array([cross, 0.0, 0.0]),                      # S = {m}
+            'closed': np.array([cross, cross, cross]),                        # S = {0..m}
+            'total': cross - np.array([0.0, 0.0, 0.0])}                       # S_full - S({m+1..}): the complements never contain input 0
+    fold = Fold(repo, 0)
+    for kind in ('first_order', 'closed', 'total'):
+        S = pd.read_csv(fold.folder / 'gpr.v.a' / 'gsa' / kind / 'S.csv', index_col=[0, 1])
+        assert [tuple(i) for i in S.index] == [(0, 0), (0, 1), (1, 0), (1, 1)]
+        np.testing.assert_allclose(S.values[1, :M], want[kind], atol=0.01, err_msg=f'{kind} (0, 1)')
+        np.testing.assert_allclose(S.values[2, :M], want[kind], atol=0.01, err_msg=f'{kind} (1, 0)')
+        np.testing.assert_allclose(S.values[3, :M], {'first_order': [1.0, 0.0, 0.0], 'closed': [1.0, 1.0, 1.0], 'total': [1.0, 1.0, 1.0]}[kind],
+                                   atol=0.01, err_msg=f'{kind} (1, 1): f = sin x1')

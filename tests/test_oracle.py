@@ -272,3 +272,29 @@ def test_known_answer_reference_test_functions(name):
     for kind, okind in (('first_order', o.FIRST_ORDER), ('closed', o.CLOSED), ('total', o.TOTAL)):
         S = o.gsa_calibrate(cal, okind, M)['S'][0, 0, :M]
         np.testing.assert_allclose(S, want[kind], atol=0.015, err_msg=f'{name} {kind}')
+
+
+def test_known_answer_cross_output_indices():
+    """The l != j entries (gsa/calibrators.py:79) for the reference's Ishigami 'standard' and 'sin' outputs (user/functions.py:144-146) are
+    known in closed form: E[f_sin | x_S] = sin x1 if input 0 is in S, else 0, so S_01(S) = (1 + B pi^4 / 5) / 2 / sqrt(Var f_standard / 2)
+    = 0.5603 for every S that contains input 0, and 0 otherwise. Oracle, two independent GPs on the same 600 points."""
+    import known_functions as kf
+    M, N = 3, 600
+    rng = np.random.default_rng(5)
+    u = (np.stack([rng.permutation(N) for _ in range(M)], axis=1) + rng.random((N, M))) / N
+    from scipy.special import ndtri
+    X = ndtri(np.clip(u, 1e-12, 1 - 1e-12))
+    fits, alphas = [], []
+    for f in (kf.ishigami(u), kf.ishigami(u, A=0.0, B=0.0)):
+        y = (f - f.mean()) / f.std() + 0.02 * rng.standard_normal(N)     # a little noise keeps the fit of the one-input function well conditioned
+        fit = o.fit(X, y, np.ones(M))                                # (from lengthscale 1: this test is about the indices, not the optimiser's path --
+        fits.append(fit)                                             # from the default 5.0 the ARD fit of Ishigami at this N stops in a poor optimum)
+        alphas.append(o.k_inv_y(X, y, fit['ell'], fit['var'], fit['noise']))
+    cal = o.ClosedSobolOracle(X, np.stack(alphas)[:, None, :], np.array([[fits[0]['var'], fits[1]['var']]]), np.stack([f['ell'] for f in fits]))
+    cross = 0.5 * (1.0 + 0.1 * np.pi ** 4 / 5.0) / np.sqrt(sum(kf.ishigami_variances().values()) * 0.5)
+    S_first = o.gsa_calibrate(cal, o.FIRST_ORDER, M)['S']
+    S_closed = o.gsa_calibrate(cal, o.CLOSED, M)['S']
+    np.testing.assert_allclose(S_first[0, 1, :M], [cross, 0.0, 0.0], atol=0.02)
+    np.testing.assert_allclose(S_first[1, 0, :M], [cross, 0.0, 0.0], atol=0.02)
+    np.testing.assert_allclose(S_closed[0, 1, :M], [cross, cross, cross], atol=0.02)
+    assert S_closed[0, 1, M] == pytest.approx(cross, abs=0.02)        # the full-model column
