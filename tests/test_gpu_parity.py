@@ -614,3 +614,21 @@ def test_fit_with_parameters_held_fixed(gpu, flags):
     u_ref = u_all.copy()
     u_ref[mask] = ref.x
     np.testing.assert_allclose(fit['lengthscales'], np.broadcast_to(softplus(u_ref[:n_ell]), (M,)), rtol=5e-3)
+
+
+@pytest.mark.parametrize('N,M', [(4097, 3), (5249, 2), (6527, 5), (8321, 6), (9300, 3), (11111, 4)])
+def test_sizes_between_the_panel_boundaries(gpu, N, M):
+    """Sizes that are no multiple of the outer panel (1024), of the tail (64 blocks) or of the far-update groups: the places where the chain's
+    schedule switches form (tail panel, lean steps, split far updates, window pieces) fall differently for each. LML and gradient against the
+    oracle (LAPACK potrf / potri), and bit-identical on a second evaluation."""
+    X, y = o.synthetic_fold(N, M, k=N % 5)
+    ell, var, noise = o.bench_hyper(M)
+    ref, gref = o.lml_and_grad_blas(X, y, ell, var, noise)
+    with gpu.RcGP(X, y) as gp:
+        gp.set_hyper(ell, var, noise)
+        lml, grad = gp.lml_grad()
+        gp.stage_gram()
+        lml2, grad2 = gp.lml_grad()
+    assert lml == pytest.approx(ref, rel=1e-10)
+    assert np.max(np.abs(grad - gref)) <= 1e-8 * np.max(np.abs(gref))
+    assert lml == lml2 and np.array_equal(grad, grad2)
