@@ -37,6 +37,18 @@ elif case == 'factor':
     assert np.all(np.triu(Lc, 1) == 0.0)
     lml_ref = o.lml(X, y, ell, var, noise)
     assert abs(gp.lml() - lml_ref) <= 1e-11 * abs(lml_ref)
+elif case == 'tall':
+    # taller than the tail (64 blocks) and than the split far update's threshold (40 blocks): outer panels with window pieces and bulk updates in
+    # front of the tail, far updates in two launches
+    N, M = 9100, 3
+    X, y = o.synthetic_fold(N, M, k=5)
+    ell, var, noise = np.array([0.9, 1.6, 2.5]), 1.2, 0.015
+    gp = _lib.RcGP(X, y)
+    gp.set_hyper(ell, var, noise)
+    lml_ref, grad_ref = o.lml_and_grad_blas(X, y, ell, var, noise)
+    lml, grad = gp.lml_grad()
+    assert abs(lml - lml_ref) <= 1e-10 * abs(lml_ref), (lml, lml_ref)
+    assert np.max(np.abs(grad - grad_ref)) <= 1e-8 * np.max(np.abs(grad_ref))
 else:
     raise SystemExit(f'unknown case {case}')
 gp.close()

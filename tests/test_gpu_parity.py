@@ -386,6 +386,14 @@ def test_fine_grained_cholesky_factor_many_panels_other_schedules(gpu, env):
     _knob_case(env, 'factor')
 
 
+@pytest.mark.parametrize('env', [{'RCGP_NB': '512', 'RCGP_EXT': '1'}, {'RCGP_EXT': '2', 'RCGP_DEPTH': '1'}, {'RCGP_NB': '1536', 'RCGP_EXT': '6', 'RCGP_DEPTH': '3'}])
+def test_tuning_knobs_on_a_matrix_taller_than_the_tail(gpu, env):
+    """The knob sets again at N = 9100 (72 blocks): outer panels with window pieces and a bulk update in front of the 64-block tail, columns
+    taller than the split far update's threshold, a chain extension of one block (the next panel's first diagonal block then gets the last
+    column's update from a window piece)."""
+    _knob_case(env, 'tall')
+
+
 def test_fine_grained_cholesky_factor_many_panels(gpu):
     """The five-stream Cholesky (diagonal chain, column work, far updates, window pieces, bulk update) over 7+ outer panels with a
     ragged last one: the factor itself, entry by entry, against LAPACK on the oracle's Gram matrix, and w = L^-1 y through the LML."""
