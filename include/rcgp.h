@@ -16,12 +16,15 @@
  *   rcgp_sobol_closed             ClosedSobol._calibrate/_V/marginalize, diagonal (l = j) term    gsa/calibrators.py:49-97
  *   rcgp_sobol_cross              the same einsum's off-diagonal (l != j) entries                 gsa/calibrators.py:79
  *   rcgp_sobol_error_terms        ClosedSobolWithError: mu_phi_mu, psi_factor, mu_psi_mu          gsa/calibrators.py:259-322
+ *   rcgp_lml_grad_batch,          the same closure / K_cho for several (fold, output) units at once: the loops   gpr/models.py:340-342,360-361
+ *   rcgp_factor_batch             over outputs and folds that the reference walks sequentially                   user/run.py:60-61,132-133
  *
  * Conventions: all matrices row-major float64; the caller owns every host buffer; the library owns device memory inside
  * the opaque handle until rcgp_destroy. A handle is bound to one device; it is not thread-safe. Distinct handles are
  * independent in what they compute, but all handles of a process on one device share one set of HIP streams (created with
  * the first handle, kept for the life of the process): their work is ordered behind each other on the device, so using two of
- * them from two threads gains nothing over using them in turn. Return value: 0 = ok; k > 0 = LAPACK-style "leading minor k is not positive
+ * them from two threads gains nothing over using them in turn -- to have one GPU work on several handles AT ONCE use the batched
+ * entries (rcgp_lml_grad_batch, rcgp_factor_batch). Return value: 0 = ok; k > 0 = LAPACK-style "leading minor k is not positive
  * definite" (TensorFlow raises InvalidArgumentError there); < 0 = bad argument (-1..-9) or HIP error (-100 - hipError_t).
  * rcgp_last_error gives the message. One process per GPU for multi-GPU runs.
  */
@@ -129,6 +132,23 @@ int rcgp_sobol_error_terms_mo(rcgp_handle h, int out_a, int out_b, int n_slices,
                               double* phi_m, double* psi_m);
 int rcgp_sobol_pair(rcgp_handle h, const double* phi_a, double pre_a, const double* alpha_a, double shift_a, const double* phi_b,
                     double pre_b, const double* alpha_b, double shift_b, int n_slices, const int32_t* slices, double* V);
+
+/* ---- several units at once on one GPU ----
+ * The reference fits its L independent outputs and its K folds one after the other (the loops at gpr/models.py:340-342, 360-361 and
+ * user/run.py:60-61, 132-133). A single factorisation of the sizes it is run at (benchmark_script.py:35-40: N <= 9840) cannot fill this
+ * chip -- its chain of N/128 diagonal-block steps is latency-bound -- so these entries run ONE schedule over n handles (units): every
+ * launch covers all units (the unit is blockIdx.z), the chains advance side by side, the update kernels of all units share the CUs.
+ * Requirements: 1 <= n <= 8 distinct single-output handles of one device with equal M and equal padded size ceil(N / 128) (N itself may
+ * differ: folds of a K-fold split), hyper-parameters set on each. A unit's numbers are bit-identical to what the single-handle call
+ * returns for it. Units whose factor (or L^-1) is still valid are not recomputed.
+ * status[u] = 0, or k > 0 when unit u's matrix is not positive definite at leading minor k (its lml / grad entries are NaN, the other
+ * units are unaffected). Return value: 0 when the call ran (look at status), < 0 for a bad argument or a HIP error (rcgp_last_error(hs[0])). */
+/* LML and gradient of every unit: lml[n], grad[n * (M + 2)] (unit-major, each as rcgp_lml_grad). */
+int rcgp_lml_grad_batch(int n, rcgp_handle* hs, double* lml, double* grad, int* status);
+/* rcgp_factor for every unit (factor, L^-1 and alpha cached on each). */
+int rcgp_factor_batch(int n, rcgp_handle* hs, int* status);
+/* Stage-level form for bench.py and the kernel tests: stage 0 = rcgp_stage_gram, 1 = rcgp_stage_potrf, 2 = rcgp_stage_trtri on all n units. */
+int rcgp_stage_batch(int stage, int n, rcgp_handle* hs);
 
 /* ---- stage-level entry points used by bench.py and the kernel tests ---- */
 int rcgp_stage_gram(rcgp_handle h);      /* Z = X/ell; A = K + noise I (lower tiles) */

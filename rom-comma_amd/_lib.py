@@ -48,6 +48,9 @@ SIGNATURES = {
     'rcgp_sobol_weight_sum': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p]),
     'rcgp_sobol_pair': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
                                        _c_double_p, ctypes.c_double, ctypes.c_int, _c_int32_p, _c_double_p]),
+    'rcgp_lml_grad_batch': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int)]),
+    'rcgp_factor_batch': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
+    'rcgp_stage_batch': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     'rcgp_stage_gram': (ctypes.c_int, [ctypes.c_void_p]),
     'rcgp_stage_potrf': (ctypes.c_int, [ctypes.c_void_p]),
     'rcgp_stage_trtri': (ctypes.c_int, [ctypes.c_void_p]),
@@ -379,6 +382,46 @@ def sobol_pair(gp: RcGP, phi_a, pre_a: float, alpha_a, shift_a: float, phi_b, pr
     gp._check(gp._lib.rcgp_sobol_pair(gp._h, _dp(phi_a), float(pre_a), _dp(alpha_a), float(shift_a), _dp(phi_b), float(pre_b), _dp(alpha_b),
                                       float(shift_b), s.shape[0], s.ctypes.data_as(_c_int32_p), _dp(V)), 'rcgp_sobol_pair')
     return V
+
+
+MAX_BATCH = 8          # RC_MAX_BATCH of the library: units per batched call
+
+
+def _handles(gps: Sequence[RcGP]):
+    if not 1 <= len(gps) <= MAX_BATCH:
+        raise ValueError(f'a batched call takes 1..{MAX_BATCH} units, got {len(gps)}')
+    return (ctypes.c_void_p * len(gps))(*[gp._h for gp in gps])
+
+
+def _batch_failure(gps: Sequence[RcGP], rc: int, what: str):
+    raise RcgpError(f'{what} failed ({rc}): {gps[0]._lib.rcgp_last_error(gps[0]._h).decode()}')
+
+
+def lml_grad_batch(gps: Sequence[RcGP]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """LML and gradient of several units in ONE schedule on the GPU (``rcgp_lml_grad_batch``): (lml (n,), grad (n, M + 2),
+    status (n,)); status[u] = k > 0 where unit u's matrix is not positive definite at leading minor k (its numbers are NaN)."""
+    n, M = len(gps), gps[0].M
+    lml, grad, status = np.empty(n), np.empty((n, M + 2)), np.zeros(n, dtype=np.int32)
+    rc = gps[0]._lib.rcgp_lml_grad_batch(n, _handles(gps), _dp(lml), _dp(grad), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if rc != 0:
+        _batch_failure(gps, rc, 'rcgp_lml_grad_batch')
+    return lml, grad, status
+
+
+def factor_batch(gps: Sequence[RcGP]) -> np.ndarray:
+    """``rcgp_factor`` for several units in one schedule; returns the status word of every unit."""
+    status = np.zeros(len(gps), dtype=np.int32)
+    rc = gps[0]._lib.rcgp_factor_batch(len(gps), _handles(gps), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if rc != 0:
+        _batch_failure(gps, rc, 'rcgp_factor_batch')
+    return status
+
+
+def stage_batch(stage: int, gps: Sequence[RcGP]):
+    """Stage 0 (Gram), 1 (Cholesky) or 2 (L^-1 + alpha) on all units (bench / kernel tests)."""
+    rc = gps[0]._lib.rcgp_stage_batch(int(stage), len(gps), _handles(gps))
+    if rc != 0:
+        _batch_failure(gps, rc, 'rcgp_stage_batch')
 
 
 def device_count() -> int:

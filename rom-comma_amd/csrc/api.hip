@@ -81,6 +81,8 @@ static void free_all(rcgp_handle_s* h) {
     if (*b) { hipFree(*b); *b = nullptr; }
   h->info = nullptr;                                       // (inside scal)
   h->FS_d = nullptr;                                       // (inside ell_d's allocation)
+  if (h->bres_d) { hipFree(h->bres_d); h->bres_d = nullptr; }
+  if (h->bres_pin) { (void)hipHostFree(h->bres_pin); h->bres_pin = nullptr; }
   if (h->pin) { (void)hipHostFree(h->pin); h->pin = nullptr; }
   if (h->ev_hyper) { (void)hipEventDestroy(h->ev_hyper); h->ev_hyper = nullptr; }
   for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
@@ -133,13 +135,15 @@ struct RcKnobs {
   bool lookahead = true, fine = true;
   int64_t nb = RC_NB_OUTER;
   int depth = 2, ext = 4;
-  std::string seen;                                    // the five values as first read, to recognise a later change
+  int tail = RC_TAIL_BLOCKS, lean = RC_LEAN_BLOCKS, farg = RC_FAR_GROUP;
+  int64_t half_tiles = RC_TRTRI_HALF_TILES;
+  std::string seen;                                    // the values as first read, to recognise a later change
 };
 static RcKnobs g_knobs;
 
 static std::string knob_string() {
   std::string out;
-  for (const char* name : {"RCGP_LOOKAHEAD", "RCGP_FINE", "RCGP_NB", "RCGP_DEPTH", "RCGP_EXT"}) {
+  for (const char* name : {"RCGP_LOOKAHEAD", "RCGP_FINE", "RCGP_NB", "RCGP_DEPTH", "RCGP_EXT", "RCGP_TAIL", "RCGP_LEAN", "RCGP_FARG", "RCGP_HALF_TILES"}) {
     const char* e = getenv(name);
     out += std::string(name) + "=" + (e ? e : "") + ";";
   }
@@ -172,6 +176,22 @@ static void read_knobs_once() {                          // (under g_streams_mut
     const int64_t nb = atoll(e);
     if (nb >= 128 && nb <= 4096 && nb % 128 == 0) g_knobs.nb = nb;
   }
+  if (const char* e = getenv("RCGP_TAIL")) {           // block columns of the fine-grained tail panel; 0 = no tail
+    const int x = atoi(e);
+    if (x >= 0 && x <= 4096) g_knobs.tail = x;
+  }
+  if (const char* e = getenv("RCGP_FARG")) {           // far updates of the panel chain in groups of this many steps
+    const int x = atoi(e);
+    if (x >= 1 && x <= 8) g_knobs.farg = x;
+  }
+  if (const char* e = getenv("RCGP_HALF_TILES")) {     // L^-1 launches of at most this many 128^2 tiles run on half tiles
+    const int64_t x = atoll(e);
+    if (x >= 0) g_knobs.half_tiles = x;
+  }
+  if (const char* e = getenv("RCGP_LEAN")) {           // chain steps with at most this many blocks below them are lean; 0 = none
+    const int x = atoi(e);
+    if (x >= 0 && x <= 4096) g_knobs.lean = x;
+  }
 }
 
 static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
@@ -201,6 +221,10 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     h->nb_outer = g_knobs.nb;
     h->chain_depth = g_knobs.depth;
     h->chain_ext = g_knobs.ext;
+    h->tail_blocks = g_knobs.tail;
+    h->lean_blocks = g_knobs.lean;
+    h->far_group = g_knobs.farg;
+    h->trtri_half_tiles = g_knobs.half_tiles;
   }
   h->launch = h->stream;
   RC_HIP(hipMalloc(&h->X, (size_t)Np * M * sizeof(double)));
@@ -440,6 +464,160 @@ RC_API int rcgp_lml_grad(rcgp_handle h, double* lml, double* grad) {
   if ((rc = rc_grad_queue(h, nrows))) return rc;
   if ((rc = rc_lml_value(h, lml))) return rc;               // the one host synchronisation of an evaluation
   return rc_grad_finish(h, grad);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched units: ONE schedule for up to RC_MAX_BATCH handles of one device with equal padded size and M (common.h, "Batched units").
+// The reference fits its L outputs and its K folds one after the other (gpr/models.py:340-342, 360-361; user/run.py:60-61); a single
+// factorisation of the sizes it is run at (N <= 10^4, benchmark_script.py:35-40) is latency-bound on this chip -- a chain of N/128 steps
+// with most CUs idle -- so the units' chains run side by side in the same launches here.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RcBatchScope {                                       // h leads `units` for the launches inside the scope
+  rcgp_handle_s* h;
+  RcBatchScope(rcgp_handle_s* lead, const std::vector<rcgp_handle_s*>& units) : h(lead) {
+    h->nb = (int)units.size();
+    for (int u = 0; u < RC_MAX_BATCH; ++u) h->bh[u] = (u < h->nb) ? units[u] : nullptr;
+  }
+  ~RcBatchScope() {
+    h->nb = 1;
+    for (int u = 0; u < RC_MAX_BATCH; ++u) h->bh[u] = nullptr;
+  }
+};
+
+static int batch_check(int n, rcgp_handle* hs, const char* who) {
+  if (n < 1 || !hs || !hs[0]) return -1;
+  rcgp_handle_s* h = hs[0];
+  if (n > RC_MAX_BATCH) { h->err = std::string(who) + ": at most " + std::to_string(RC_MAX_BATCH) + " units per call"; return -2; }
+  for (int u = 0; u < n; ++u) {
+    if (!hs[u]) { h->err = std::string(who) + ": null handle"; return -2; }
+    if (hs[u]->L != 1) { h->err = std::string(who) + ": single-output handles only"; return -2; }
+    if (hs[u]->device != h->device || hs[u]->Np != h->Np || hs[u]->M != h->M) {
+      h->err = std::string(who) + ": the units of a batch must share the device, the padded size (ceil(N / 128)) and M";
+      return -2;
+    }
+    for (int v = 0; v < u; ++v)
+      if (hs[v] == hs[u]) { h->err = std::string(who) + ": the same handle twice"; return -2; }
+    if (!hs[u]->hyper_set) { h->err = hs[u]->err = "hyper-parameters not set: call rcgp_set_hyper first"; return -5; }
+  }
+  if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return -3; }
+  return 0;
+}
+
+// Gram + factorisation for the units that have no factor, L^-1 + alpha for those that lack them: each stage one batched schedule.
+static int batch_ensure(int n, rcgp_handle* hs, bool want_inverse) {
+  int rc;
+  std::vector<rcgp_handle_s*> todo;
+  for (int u = 0; u < n; ++u)
+    if (!hs[u]->factored) todo.push_back(hs[u]);
+  if (!todo.empty()) {
+    rcgp_handle_s* h = todo[0];
+    RcBatchScope scope(h, todo);
+    if ((rc = rc_launch_scale(h)) || (rc = rc_launch_gram(h))) { hs[0]->err = h->err; return rc; }
+    for (auto hu : todo) { hu->factored = hu->inverted = false; hu->gram_fresh = true; }
+    if ((rc = rc_potrf(h))) { hs[0]->err = h->err; return rc; }
+  }
+  if (!want_inverse) return 0;
+  todo.clear();
+  for (int u = 0; u < n; ++u)
+    if (!hs[u]->inverted) todo.push_back(hs[u]);
+  if (!todo.empty()) {
+    rcgp_handle_s* h = todo[0];
+    RcBatchScope scope(h, todo);
+    if ((rc = rc_trtri(h)) || (rc = rc_alpha(h))) { hs[0]->err = h->err; return rc; }
+    for (auto hu : todo) hu->inverted = true;
+  }
+  return 0;
+}
+
+// The numbers of a batched evaluation: every unit's LML sums, gradient sums and status word gathered into the leader's result table,
+// ONE copy into pinned memory, ONE synchronisation. status[u] = 0 or the leading minor that failed (that unit's factor is dropped).
+static int batch_values(int n, rcgp_handle* hs, double* lml, double* grad, int* status) {
+  rcgp_handle_s* h = hs[0];
+  if (!h->bres_d) {
+    RC_HIP(hipMalloc(&h->bres_d, (size_t)RC_MAX_BATCH * RC_SCAL_ELEMS * sizeof(double)));
+    RC_HIP(hipHostMalloc(&h->bres_pin, (size_t)RC_MAX_BATCH * RC_SCAL_ELEMS * sizeof(double), hipHostMallocDefault));
+  }
+  std::vector<rcgp_handle_s*> units(hs, hs + n);
+  {
+    RcBatchScope scope(h, units);
+    int rc = rc_batch_lml_reduce(h);
+    if (rc) return rc;
+  }
+  RC_HIP(hipMemcpyAsync(h->bres_pin, h->bres_d, (size_t)n * RC_SCAL_ELEMS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RC_HIP(hipStreamSynchronize(h->stream));
+  if (h->profiling) rc_prof_collect(h);
+  const int M = h->M;
+  for (int u = 0; u < n; ++u) {
+    const double* host = h->bres_pin + (size_t)u * RC_SCAL_ELEMS;
+    int info = 0;
+    memcpy(&info, host + RC_SCAL_INFO, sizeof(int));
+    status[u] = info;
+    if (info != 0) {
+      hs[u]->err = "matrix is not positive definite: leading minor " + std::to_string(info);
+      hs[u]->factored = hs[u]->inverted = false;
+      if (lml) lml[u] = NAN;
+      if (grad) for (int m = 0; m < M + 2; ++m) grad[(size_t)u * (M + 2) + m] = NAN;
+      continue;
+    }
+    if (lml) lml[u] = -0.5 * host[0] - host[1] - 0.5 * (double)hs[u]->N * 1.8378770664093454836;   // log(2 pi)
+    if (grad) {
+      double* g = grad + (size_t)u * (M + 2);
+      for (int m = 0; m < M; ++m) g[m] = 0.5 * host[8 + m] / hs[u]->ell[m];     // dK/dell_m = K (z_im - z_jm)^2 / ell_m
+      g[M] = 0.5 * host[8 + M] / hs[u]->var;
+      g[M + 1] = 0.5 * host[8 + M + 1];
+    }
+  }
+  return 0;
+}
+
+RC_API int rcgp_lml_grad_batch(int n, rcgp_handle* hs, double* lml, double* grad, int* status) {
+  int rc;
+  if ((rc = batch_check(n, hs, "rcgp_lml_grad_batch"))) return rc;
+  if (!lml || !grad || !status) { hs[0]->err = "rcgp_lml_grad_batch: null argument"; return -2; }
+  if ((rc = batch_ensure(n, hs, true))) return rc;
+  rcgp_handle_s* h = hs[0];
+  std::vector<rcgp_handle_s*> units(hs, hs + n);
+  {
+    RcBatchScope scope(h, units);
+    int nrows = 0;
+    if ((rc = rc_launch_grad(h, &nrows)) || (rc = rc_grad_queue(h, nrows))) return rc;
+  }
+  return batch_values(n, hs, lml, grad, status);
+}
+
+RC_API int rcgp_factor_batch(int n, rcgp_handle* hs, int* status) {
+  int rc;
+  if ((rc = batch_check(n, hs, "rcgp_factor_batch"))) return rc;
+  if (!status) { hs[0]->err = "rcgp_factor_batch: null argument"; return -2; }
+  if ((rc = batch_ensure(n, hs, true))) return rc;
+  return batch_values(n, hs, nullptr, nullptr, status);
+}
+
+RC_API int rcgp_stage_batch(int stage, int n, rcgp_handle* hs) {
+  int rc;
+  if ((rc = batch_check(n, hs, "rcgp_stage_batch"))) return rc;
+  rcgp_handle_s* h = hs[0];
+  std::vector<rcgp_handle_s*> units(hs, hs + n);
+  RcBatchScope scope(h, units);
+  switch (stage) {
+    case 0:
+      if ((rc = rc_launch_scale(h)) || (rc = rc_launch_gram(h))) return rc;
+      for (auto hu : units) { hu->factored = hu->inverted = false; hu->gram_fresh = true; }
+      return 0;
+    case 1:
+      for (auto hu : units)
+        if (!hu->gram_fresh) { h->err = "rcgp_stage_batch: no fresh Gram matrix on every unit (stage 0 first; a factorisation consumes it)"; return -5; }
+      return rc_potrf(h);
+    case 2:
+      for (auto hu : units)
+        if (!hu->factored) { h->err = "rcgp_stage_batch: a unit has no Cholesky factor"; return -5; }
+      if ((rc = rc_trtri(h)) || (rc = rc_alpha(h))) return rc;
+      for (auto hu : units) hu->inverted = true;
+      return 0;
+    default:
+      h->err = "rcgp_stage_batch: stage must be 0 (Gram), 1 (Cholesky) or 2 (L^-1 + alpha)";
+      return -2;
+  }
 }
 
 RC_API int rcgp_factor(rcgp_handle h) {

@@ -30,8 +30,21 @@
 #define RC_LEAN_BLOCKS 40
 #endif
 #define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
+#define RC_MAX_BATCH 8         // most units (handles of equal padded size on one device) that one batched evaluation takes (rcgp_lml_grad_batch)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched units. Every kernel on the evaluation path (Gram, the whole factorisation, L^-1, alpha, K^-1 / gradient, the reductions) takes
+// its per-unit pointers as a small table in the kernel arguments and picks its unit from blockIdx.z: ONE schedule -- the same launches on the
+// same five streams in the same order -- serves 1..RC_MAX_BATCH independent units of equal padded size, so that the latency-bound chain
+// steps of a factorisation (one workgroup per unit and step) cost what they cost for one unit and the column / update kernels of all
+// units fill the chip together. A unit's arithmetic does not depend on who shares the launch: its results are bit-identical to a
+// launch of its own. (Reference: the loops over outputs and folds that the reference runs one after the other, gpr/models.py:340-342,
+// 360-361, user/run.py:60-61.)
+// ---------------------------------------------------------------------------------------------------------------------
+template <class T> struct RcBP { T* p[RC_MAX_BATCH]; };      // one pointer per unit
+struct RcBN { int64_t v[RC_MAX_BATCH]; };                    // one count per unit (valid rows N: units share Np and M, not necessarily N)
 
 // Profiled kernel classes (rcgp_profile_get). Order is part of the ABI (include/rcgp.h).
 enum RcKernelClass {
@@ -60,13 +73,14 @@ struct rcgp_handle_s {
   int prof_pending = -1;             // index of the profiling bracket whose events the next RC_LAUNCH carries
   std::vector<hipEvent_t> la_events; // look-ahead dependency events (no timing), handed out in order by next_event (potrf.hip)
   size_t la_cursor = 0;
-  // the five run-time knobs of the factorisation's schedule (environment, read once per process: api.hip)
+  // the run-time knobs of the factorisation's schedule (environment, read ONCE per process: api.hip): RCGP_LOOKAHEAD, RCGP_FINE, RCGP_NB,
+  // RCGP_DEPTH, RCGP_EXT, RCGP_TAIL, RCGP_LEAN. far_split_min and far_group are compile-time only (-DRC_FAR_SPLIT_MIN, -DRC_FAR_GROUP).
   bool lookahead = true;             // RCGP_LOOKAHEAD: 0 = strictly sequential potrf on the main stream
   bool fine_chain = true;            // RCGP_FINE: 0 = one stream per panel chain (D, T, G in order), one-panel look-ahead
   int64_t nb_outer = RC_NB_OUTER;    // RCGP_NB: outer panel width
   int chain_depth = 2;               // RCGP_DEPTH >= 1: column panels updated by their own kernels ahead of the bulk trailing update
-  int tail_blocks = RC_TAIL_BLOCKS;   // the last this-many block columns of the factorisation form one fine-grained panel (potrf.hip)
-  int lean_blocks = RC_LEAN_BLOCKS;   // chain steps with at most this many blocks below them carry ONE completion signal (potrf.hip)
+  int tail_blocks = RC_TAIL_BLOCKS;   // RCGP_TAIL: the last this-many block columns of the factorisation form one fine-grained panel (potrf.hip)
+  int lean_blocks = RC_LEAN_BLOCKS;   // RCGP_LEAN: chain steps with at most this many blocks below them carry ONE completion signal (potrf.hip)
   int far_split_min = RC_FAR_SPLIT_MIN;   // columns taller than this many blocks: a far update as two launches (potrf.hip)
   int far_group = RC_FAR_GROUP;      // far updates of the panel chain in groups of this many steps (K = 128 x group), potrf.hip
   int chain_ext = 4;                 // RCGP_EXT >= 1: 128-blocks past its own panel that a chain step keeps up to date
@@ -123,8 +137,32 @@ struct rcgp_handle_s {
   double prof_ms[RC_K_COUNT] = {0, 0, 0, 0, 0, 0};
   long prof_count[RC_K_COUNT] = {0, 0, 0, 0, 0, 0};
   double prof_work[RC_K_COUNT] = {0, 0, 0, 0, 0, 0};   // algorithmic flops (GEMM) or bytes (Gram) or pair-terms (Sobol)
+  // batch: the units a launch covers while this handle leads a batched call (api.hip: RcBatchScope). bh[0] == this.
+  int nb = 1;
+  rcgp_handle_s* bh[RC_MAX_BATCH] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* bres_d = nullptr;    // RC_MAX_BATCH x RC_SCAL_ELEMS: the result blocks of a batched evaluation led by this handle (allocated on first use)
+  double* bres_pin = nullptr;  // ... and their pinned host copy
   std::string err;
 };
+
+// Per-unit pointer tables for a launch led by h: `ptr` points into one of the LEADER's device buffers; unit u gets the same offset in its own
+// buffer of that name. (The schedule code computes every address from the leader's buffers and knows nothing of batches.)
+int rc_bp_bytes(rcgp_handle_s* h, const void* ptr, void** out);
+template <class T> inline int rc_bp(rcgp_handle_s* h, T* ptr, RcBP<T>& out) {
+  if (h->nb <= 1) { out.p[0] = ptr; for (int u = 1; u < RC_MAX_BATCH; ++u) out.p[u] = nullptr; return 0; }
+  return rc_bp_bytes(h, (const void*)ptr, (void**)out.p);
+}
+inline RcBN rc_bn(rcgp_handle_s* h) {
+  RcBN n;
+  for (int u = 0; u < RC_MAX_BATCH; ++u) n.v[u] = (u < h->nb && h->nb > 1) ? h->bh[u]->N : h->N;
+  return n;
+}
+#define RC_BP(T, name, ptr)                          \
+  RcBP<T> name;                                      \
+  {                                                  \
+    const int rcbp_ = rc_bp<T>(h, (ptr), name);      \
+    if (rcbp_) return rcbp_;                         \
+  }
 
 #define RC_HIP(call)                                                                       \
   do {                                                                                     \
@@ -227,6 +265,7 @@ int rc_sobol_weight_sum(rcgp_handle_s* h, const double* phi, double pre, const d
 int rc_sobol_pair(rcgp_handle_s* h, const double* phi_a, double pre_a, const double* alpha_a, double shift_a, const double* phi_b,
                   double pre_b, const double* alpha_b, double shift_b, int n_slices, const int32_t* slices, double* V_host);
 int rc_grad_queue(rcgp_handle_s* h, int nrows);              // queue the gradient's final reduction (before rc_lml_value)
+int rc_batch_lml_reduce(rcgp_handle_s* h);                   // batched evaluation: every unit's result block -> the leader's h->bres_d
 int rc_grad_finish(rcgp_handle_s* h, double* grad);          // host: gradient from the pinned result block (after rc_lml_value)
 int rc_grad_queue_mo(rcgp_handle_s* h);
 int rc_grad_finish_mo(rcgp_handle_s* h, double* g_ell, double* g_F, double* g_S);

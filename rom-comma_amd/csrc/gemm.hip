@@ -220,8 +220,10 @@ __device__ __forceinline__ void acc_store_staged(const v4d (&acc)[4][Geo<WN>::NI
 // the MFMA chain, so the epilogue is stores only.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int WN, int STAGED>
-__global__ void RC_BOUNDS(WN) k_syrk_lower(double* __restrict__ C, int64_t ldc, const double* __restrict__ P, int64_t ldp, int kk) {
+__global__ void RC_BOUNDS(WN) k_syrk_lower(RcBP<double> Cb, int64_t ldc, RcBP<const double> Pb, int64_t ldp, int kk) {
   __shared__ double lds[GEMM_LDS];
+  double* __restrict__ C = Cb.p[blockIdx.z];
+  const double* __restrict__ P = Pb.p[blockIdx.z];
   int ti, tj;
   tri_decode(blockIdx.x, ti, tj);
   v4d acc[4][Geo<WN>::NI];
@@ -234,9 +236,11 @@ __global__ void RC_BOUNDS(WN) k_syrk_lower(double* __restrict__ C, int64_t ldc, 
 int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double* P, int64_t ldp, int64_t n, int64_t kk) {
   const int64_t T = n / 128;
   if (T <= 0) return 0;
-  RcProfScope ps(h, RC_K_GEMM, (double)n * (double)(n + 128) * (double)kk, true);   // 2*kk flops per lower-tile element
-  const dim3 grid((unsigned)(T * (T + 1) / 2)), block(128 * RC_WN);
-  RC_LAUNCH((k_syrk_lower<RC_WN, 3>), grid, block, 0, C, ldc, P, ldp, (int)kk);
+  RC_BP(double, Cb, C)
+  RC_BP(const double, Pb, P)
+  RcProfScope ps(h, RC_K_GEMM, (double)h->nb * (double)n * (double)(n + 128) * (double)kk, true);   // 2*kk flops per lower-tile element
+  const dim3 grid((unsigned)(T * (T + 1) / 2), 1, (unsigned)h->nb), block(128 * RC_WN);
+  RC_LAUNCH((k_syrk_lower<RC_WN, 3>), grid, block, 0, Cb, ldc, Pb, ldp, (int)kk);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -245,11 +249,14 @@ int rc_launch_syrk_lower(rcgp_handle_s* h, double* C, int64_t ldc, const double*
 // C (m x n) -= A (m x kk) * B (n x kk)^T, skipping tiles strictly above the global diagonal.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int WN, int STAGED>
-__global__ void RC_BOUNDS(WN) k_gemm_nt_sub(double* __restrict__ C, int64_t ldc, const double* __restrict__ A, int64_t lda,
-                                            const double* __restrict__ B, int64_t ldb, int kk, int64_t row0, int64_t col0) {
+__global__ void RC_BOUNDS(WN) k_gemm_nt_sub(RcBP<double> Cb, int64_t ldc, RcBP<const double> Ab, int64_t lda, RcBP<const double> Bb, int64_t ldb,
+                                            int kk, int64_t row0, int64_t col0) {
   __shared__ double lds[GEMM_LDS];
   const int tj = blockIdx.x, ti = blockIdx.y;
   if (col0 + (int64_t)tj * 128 > row0 + (int64_t)ti * 128) return;
+  double* __restrict__ C = Cb.p[blockIdx.z];
+  const double* __restrict__ A = Ab.p[blockIdx.z];
+  const double* __restrict__ B = Bb.p[blockIdx.z];
   v4d acc[4][Geo<WN>::NI];
   double* Ct = C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128;
   if (STAGED & 1) acc_load_staged<WN>(acc, Ct, ldc, lds); else acc_load<WN>(acc, Ct, ldc);
@@ -261,11 +268,14 @@ __global__ void RC_BOUNDS(WN) k_gemm_nt_sub(double* __restrict__ C, int64_t ldc,
 // 13.7 us of MFMA time per CU behind a C tile and eight operand slabs that have to arrive first; with two workgroups per CU that took 23-27 us
 // per tile. Half tiles: 32 accumulator registers, the C half tile and the first four operand slabs requested up front (register ring as in
 // gemm_mainloop_m64, both operands k-contiguous), two workgroups per CU at <= 128 registers.
-__global__ void __launch_bounds__(512, 4) k_gemm_nt_sub_h64(double* __restrict__ C, int64_t ldc, const double* __restrict__ A, int64_t lda,
-                                                             const double* __restrict__ B, int64_t ldb, int kk, int64_t row0, int64_t col0) {
+__global__ void __launch_bounds__(512, 4) k_gemm_nt_sub_h64(RcBP<double> Cb, int64_t ldc, RcBP<const double> Ab, int64_t lda, RcBP<const double> Bb,
+                                                             int64_t ldb, int kk, int64_t row0, int64_t col0) {
   __shared__ double lds[2 * 3 * 64 * LDK];                      // two stages of A [64][LDK] + B [128][LDK]
   const int tj = blockIdx.x, th = blockIdx.y;
   if (col0 + (int64_t)tj * 128 > row0 + (int64_t)th * 64) return;    // (row0, col0 multiples of 128: a half tile is below the diagonal with its tile)
+  double* __restrict__ C = Cb.p[blockIdx.z];
+  const double* __restrict__ A = Ab.p[blockIdx.z];
+  const double* __restrict__ B = Bb.p[blockIdx.z];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;
   const int fr = lane & 15, fq = lane >> 4;
@@ -340,12 +350,16 @@ __global__ void __launch_bounds__(512, 4) k_gemm_nt_sub_h64(double* __restrict__
 int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                           int64_t m, int64_t n, int64_t kk, int64_t row0, int64_t col0) {
   if (m <= 0 || n <= 0) return 0;
-  RcProfScope ps(h, RC_K_GEMM, 2.0 * (double)m * (double)n * (double)kk, true);
+  RC_BP(double, Cb, C)
+  RC_BP(const double, Ab, A)
+  RC_BP(const double, Bb, B)
+  RcProfScope ps(h, RC_K_GEMM, (double)h->nb * 2.0 * (double)m * (double)n * (double)kk, true);
   if (kk <= 512 && kk % 64 == 0) {     // the panel chain's near / far updates (K = 128 ... 512): half tiles, everything requested up front
-    RC_LAUNCH(k_gemm_nt_sub_h64, dim3((unsigned)(n / 128), (unsigned)(m / 64)), dim3(512), 0, C, ldc, A, lda, B, ldb, (int)kk, row0, col0);
-  } else {
-    RC_LAUNCH((k_gemm_nt_sub<RC_WN, 3>), dim3((unsigned)(n / 128), (unsigned)(m / 128)), dim3(128 * RC_WN), 0, C, ldc, A, lda, B, ldb, (int)kk, row0,
+    RC_LAUNCH(k_gemm_nt_sub_h64, dim3((unsigned)(n / 128), (unsigned)(m / 64), (unsigned)h->nb), dim3(512), 0, Cb, ldc, Ab, lda, Bb, ldb, (int)kk, row0,
               col0);
+  } else {
+    RC_LAUNCH((k_gemm_nt_sub<RC_WN, 3>), dim3((unsigned)(n / 128), (unsigned)(m / 128), (unsigned)h->nb), dim3(128 * RC_WN), 0, Cb, ldc, Ab, lda, Bb, ldb,
+              (int)kk, row0, col0);
   }
   RC_HIP(hipGetLastError());
   return 0;
@@ -357,8 +371,10 @@ int rc_launch_gemm_nt_sub(rcgp_handle_s* h, double* C, int64_t ldc, const double
 // the 16 lanes of a fragment read are 16 rows of one k), every global load in flight before the first wait.
 // ---------------------------------------------------------------------------------------------------------------------
 #define LP 129
-__global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, double* D, int64_t ld) {
+__global__ void __launch_bounds__(256) k_prep2(RcBP<const double> Ltb, RcBP<double> Db, int64_t ld) {
   extern __shared__ double sm2[];                  // La[32][LP], Lb[32][LP]
+  const double* __restrict__ Lt = Ltb.p[blockIdx.z];
+  double* D = Db.p[blockIdx.z];
   double* La = sm2;
   double* Lb = La + 32 * LP;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
@@ -427,9 +443,14 @@ __global__ void __launch_bounds__(256) k_prep2(const double* __restrict__ Lt, do
 __device__ __forceinline__ int rc_packed_block(int rb, int cb) { return rb * (rb + 1) / 2 + cb; }
 
 template <int NS>
-__global__ void __launch_bounds__(512, 4) k_trsm_subst(double* __restrict__ P, int64_t ldp, const double* __restrict__ Ljj, int64_t ldl,
-                                                        const double* __restrict__ invL, double* __restrict__ rhs, const double* __restrict__ wj) {
+__global__ void __launch_bounds__(512, 4) k_trsm_subst(RcBP<double> Pb, int64_t ldp, RcBP<const double> Ljjb, int64_t ldl, RcBP<const double> invLb,
+                                                        RcBP<double> rhsb, RcBP<const double> wjb) {
   extern __shared__ double smts[];                 // Lp[36][PB], wv[128]
+  double* __restrict__ P = Pb.p[blockIdx.z];
+  const double* __restrict__ Ljj = Ljjb.p[blockIdx.z];
+  const double* __restrict__ invL = invLb.p[blockIdx.z];
+  double* __restrict__ rhs = rhsb.p[blockIdx.z];
+  const double* __restrict__ wj = wjb.p[blockIdx.z];
   double* Lp = smts;
   double* wv = Lp + 36 * PB;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
@@ -506,8 +527,13 @@ int rc_launch_trsm_subst(rcgp_handle_s* h, double* P, int64_t ldp, const double*
     RC_HIP(hipFuncSetAttribute((const void*)k_trsm_subst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_SUBST_LDS));
     h->subst_attr_set = true;
   }
-  RcProfScope ps(h, RC_K_GEMM, (double)m * 128.0 * 128.0, true);
-  RC_LAUNCH(k_trsm_subst<4>, dim3((unsigned)(m / 64)), dim3(512), RC_SUBST_LDS, P, ldp, Ljj, ldp, invL, rhs, wj);
+  RC_BP(double, Pb, P)
+  RC_BP(const double, Lb, Ljj)
+  RC_BP(const double, ib, invL)
+  RC_BP(double, rb, rhs)
+  RC_BP(const double, wb, wj)
+  RcProfScope ps(h, RC_K_GEMM, (double)h->nb * (double)m * 128.0 * 128.0, true);
+  RC_LAUNCH(k_trsm_subst<4>, dim3((unsigned)(m / 64), 1, (unsigned)h->nb), dim3(512), RC_SUBST_LDS, Pb, ldp, Lb, ldp, ib, rb, wb);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -526,14 +552,21 @@ int rc_launch_chain_tile(rcgp_handle_s* h, double* T, double* D, int64_t ld, con
     RC_HIP(hipFuncSetAttribute((const void*)k_prep2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     h->prep_attr_set = true;
   }
+  RC_BP(double, Tb, T)
+  RC_BP(const double, Tcb, (const double*)T)
+  RC_BP(double, Db, D)
+  RC_BP(const double, Lb, Ljj)
+  RC_BP(const double, ib, invL)
+  RC_BP(double, rb, rhs)
+  RC_BP(const double, wb, wj)
   {
-    RcProfScope ps(h, RC_K_GEMM, 128.0 * 128.0 * 128.0, true);
-    RC_LAUNCH(k_trsm_subst<1>, dim3(8), dim3(512), RC_SUBST_LDS, T, ld, Ljj, ld, invL, rhs, wj);
+    RcProfScope ps(h, RC_K_GEMM, (double)h->nb * 128.0 * 128.0 * 128.0, true);
+    RC_LAUNCH(k_trsm_subst<1>, dim3(8, 1, (unsigned)h->nb), dim3(512), RC_SUBST_LDS, Tb, ld, Lb, ld, ib, rb, wb);
     RC_HIP(hipGetLastError());
   }
   {
-    RcProfScope ps(h, RC_K_GEMM, 128.0 * 129.0 * 128.0, true);
-    RC_LAUNCH(k_prep2, dim3(10), dim3(256), lds2, (const double*)T, D, ld);
+    RcProfScope ps(h, RC_K_GEMM, (double)h->nb * 128.0 * 129.0 * 128.0, true);
+    RC_LAUNCH(k_prep2, dim3(10, 1, (unsigned)h->nb), dim3(256), lds2, Tcb, Db, ld);
     RC_HIP(hipGetLastError());
   }
   return 0;
@@ -544,12 +577,16 @@ int rc_launch_chain_tile(rcgp_handle_s* h, double* T, double* D, int64_t ld, con
 // Level s: for each pair p (colA = 2ps, rowC = colA + s):  T = B * A^-1 -> S ; X21 = -C^-1 * T -> W.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int WN>
-__global__ void RC_BOUNDS(WN) k_trtri_T(const double* __restrict__ Lm, const double* __restrict__ W, double* __restrict__ S, int64_t ld,
-                                        int64_t Np, int64_t s, int pair0, int ti0) {
+__global__ void RC_BOUNDS(WN) k_trtri_T(RcBP<const double> Lmb, RcBP<const double> Wb, RcBP<double> Sb, int64_t ld, int64_t Np, int64_t s, int pair0,
+                                        int ti0, int npairs) {
   __shared__ double lds[GEMM_LDS];
   const int ti = ti0 + blockIdx.x, tj = blockIdx.y;           // tj slow: the longest k-ranges (small tj) are dispatched first
-  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z), rowC = colA + s;
+  const int unit = blockIdx.z / npairs;                       // blockIdx.z = unit * npairs + pair
+  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z - unit * npairs), rowC = colA + s;
   if (rowC + (int64_t)ti * 128 >= Np) return;
+  const double* __restrict__ Lm = Lmb.p[unit];
+  const double* __restrict__ W = Wb.p[unit];
+  double* __restrict__ S = Sb.p[unit];
   v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
   // A operand: B block of L, element (i,k) at Lm[(rowC+i)*ld + colA + k]; B operand: A^-1 element (k,j) at W[(colA+k)*ld + colA + j]
@@ -559,11 +596,14 @@ __global__ void RC_BOUNDS(WN) k_trtri_T(const double* __restrict__ Lm, const dou
 }
 
 template <int WN>
-__global__ void RC_BOUNDS(WN) k_trtri_X(double* __restrict__ W, const double* __restrict__ S, int64_t ld, int64_t Np, int64_t s, int pair0) {
+__global__ void RC_BOUNDS(WN) k_trtri_X(RcBP<double> Wb, RcBP<const double> Sb, int64_t ld, int64_t Np, int64_t s, int pair0, int npairs) {
   __shared__ double lds[GEMM_LDS];
   const int tj = blockIdx.x, ti = (int)gridDim.y - 1 - (int)blockIdx.y;   // ti slow and reversed: longest k-ranges first
-  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z), rowC = colA + s;
+  const int unit = blockIdx.z / npairs;
+  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z - unit * npairs), rowC = colA + s;
   if (rowC + (int64_t)ti * 128 >= Np) return;
+  double* __restrict__ W = Wb.p[unit];
+  const double* __restrict__ S = Sb.p[unit];
   v4d acc[4][Geo<WN>::NI];
   acc_zero(acc);
   // A operand: C^-1 element (i,k) at W[(rowC+i)*ld + rowC + k], zero for k > i; B operand: T element (k,j) at S[(rowC+k)*ld + colA + j]
@@ -651,12 +691,16 @@ __device__ __forceinline__ void acc_store_m64(const v4d (&acc)[2][2], double* __
       for (int r = 0; r < 4; ++r) Ct[(int64_t)(wr + 16 * mi + 4 * r + fq) * ldc + wc + 16 * ni + fr] = acc[mi][ni][r];
 }
 
-__global__ void __launch_bounds__(512, 4) k_trtri_T_half(const double* __restrict__ Lm, const double* __restrict__ W, double* __restrict__ S,
-                                                          int64_t ld, int64_t Np, int64_t s, int pair0) {
+__global__ void __launch_bounds__(512, 4) k_trtri_T_half(RcBP<const double> Lmb, RcBP<const double> Wb, RcBP<double> Sb, int64_t ld, int64_t Np,
+                                                          int64_t s, int pair0, int npairs) {
   __shared__ double lds[GEMM_LDS];
   const int th = blockIdx.x, tj = blockIdx.y;                 // th: 64-row half tile of the C part; tj slow: longest k-ranges first
-  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z), rowC = colA + s;
+  const int unit = blockIdx.z / npairs;
+  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z - unit * npairs), rowC = colA + s;
   if (rowC + (int64_t)th * 64 >= Np) return;
+  const double* __restrict__ Lm = Lmb.p[unit];
+  const double* __restrict__ W = Wb.p[unit];
+  double* __restrict__ S = Sb.p[unit];
   v4d acc[2][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -664,12 +708,15 @@ __global__ void __launch_bounds__(512, 4) k_trtri_T_half(const double* __restric
   acc_store_m64(acc, S + (rowC + (int64_t)th * 64) * ld + colA + (int64_t)tj * 128, ld);
 }
 
-__global__ void __launch_bounds__(512, 4) k_trtri_X_half(double* __restrict__ W, const double* __restrict__ S, int64_t ld, int64_t Np, int64_t s,
-                                                          int pair0) {
+__global__ void __launch_bounds__(512, 4) k_trtri_X_half(RcBP<double> Wb, RcBP<const double> Sb, int64_t ld, int64_t Np, int64_t s, int pair0,
+                                                          int npairs) {
   __shared__ double lds[GEMM_LDS];
   const int tj = blockIdx.x, th = (int)gridDim.y - 1 - (int)blockIdx.y;     // th slow and reversed: longest k-ranges first
-  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z), rowC = colA + s;
+  const int unit = blockIdx.z / npairs;
+  const int64_t colA = 2 * s * (int64_t)(pair0 + blockIdx.z - unit * npairs), rowC = colA + s;
   if (rowC + (int64_t)th * 64 >= Np) return;
+  double* __restrict__ W = Wb.p[unit];
+  const double* __restrict__ S = Sb.p[unit];
   v4d acc[2][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -682,15 +729,21 @@ __global__ void __launch_bounds__(512, 4) k_trtri_X_half(double* __restrict__ W,
 int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti0, int nti) {
   if (npairs <= 0 || nti <= 0) return 0;
   const int64_t st = s / 128;
-  RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)nti * 128.0 * (double)s * (double)s);
+  RC_BP(const double, Ab, h->A)
+  RC_BP(const double, Wb, h->Linv)
+  RC_BP(double, Sb, h->S)
+  RcProfScope ps(h, RC_K_GEMM, (double)h->nb * (double)npairs * (double)nti * 128.0 * (double)s * (double)s);
+  // (half tiles by the tile count of ONE unit. Both forms add up a tile's k-slabs in the same order, so which one runs does not change a
+  // bit of the result; measured with 2 and 4 units per launch the half tiles stay the faster form at these sizes: N = 8192, 4 units,
+  // L^-1 12.3 ms with them, 12.8 without)
   if (ti0 == 0 && (int64_t)npairs * nti * st <= h->trtri_half_tiles) {
-    hipLaunchKernelGGL(k_trtri_T_half, dim3((unsigned)(2 * nti), (unsigned)st, (unsigned)npairs), dim3(512), 0, h->launch, h->A, h->Linv, h->S, h->Np,
-                       h->Np, s, pair0);
+    hipLaunchKernelGGL(k_trtri_T_half, dim3((unsigned)(2 * nti), (unsigned)st, (unsigned)(npairs * h->nb)), dim3(512), 0, h->launch, Ab, Wb, Sb, h->Np,
+                       h->Np, s, pair0, npairs);
     RC_HIP(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(k_trtri_T<RC_WN>, dim3((unsigned)nti, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->launch, h->A, h->Linv, h->S,
-                     h->Np, h->Np, s, pair0, ti0);
+  hipLaunchKernelGGL(k_trtri_T<RC_WN>, dim3((unsigned)nti, (unsigned)st, (unsigned)(npairs * h->nb)), dim3(128 * RC_WN), 0, h->launch, Ab, Wb, Sb,
+                     h->Np, h->Np, s, pair0, ti0, npairs);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -698,15 +751,17 @@ int rc_launch_trtri_T(rcgp_handle_s* h, int64_t s, int pair0, int npairs, int ti
 int rc_launch_trtri_X(rcgp_handle_s* h, int64_t s, int pair0, int npairs) {
   if (npairs <= 0) return 0;
   const int64_t st = s / 128;
-  RcProfScope ps(h, RC_K_GEMM, (double)npairs * (double)s * (double)s * (double)s);
+  RC_BP(double, Wb, h->Linv)
+  RC_BP(const double, Sb, h->S)
+  RcProfScope ps(h, RC_K_GEMM, (double)h->nb * (double)npairs * (double)s * (double)s * (double)s);
   if ((int64_t)npairs * st * st <= h->trtri_half_tiles) {
-    hipLaunchKernelGGL(k_trtri_X_half, dim3((unsigned)st, (unsigned)(2 * st), (unsigned)npairs), dim3(512), 0, h->launch, h->Linv, h->S, h->Np, h->Np, s,
-                       pair0);
+    hipLaunchKernelGGL(k_trtri_X_half, dim3((unsigned)st, (unsigned)(2 * st), (unsigned)(npairs * h->nb)), dim3(512), 0, h->launch, Wb, Sb, h->Np, h->Np,
+                       s, pair0, npairs);
     RC_HIP(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(k_trtri_X<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)npairs), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->S, h->Np,
-                     h->Np, s, pair0);
+  hipLaunchKernelGGL(k_trtri_X<RC_WN>, dim3((unsigned)st, (unsigned)st, (unsigned)(npairs * h->nb)), dim3(128 * RC_WN), 0, h->launch, Wb, Sb, h->Np,
+                     h->Np, s, pair0, npairs);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -719,9 +774,15 @@ int rc_launch_trtri_X(rcgp_handle_s* h, int64_t s, int pair0, int npairs) {
 // Tiles go out in row order of the lower triangle, heaviest k-ranges first by construction of tri_decode's enumeration (an 8 x 8
 // super-block order per XCD was measured: HBM reads -7 %, time +13 % -- DESIGN.md Appendix A.3).
 template <int LZ, int WN>
-__global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld, int64_t Np, int64_t N, int M, const double* __restrict__ Z,
-                                     const double* __restrict__ sq, const double* __restrict__ alpha, double var,
-                                     double* __restrict__ partial) {
+__global__ void RC_BOUNDS(WN) k_grad(RcBP<const double> Linvb, int64_t ld, int64_t Np, RcBN Nv, int M, RcBP<const double> Zb, RcBP<const double> sqb,
+                                     RcBP<const double> alphab, RcBP<const double> FSb, RcBP<double> partialb) {
+  const double* __restrict__ Linv = Linvb.p[blockIdx.z];
+  const double* __restrict__ Z = Zb.p[blockIdx.z];
+  const double* __restrict__ sq = sqb.p[blockIdx.z];
+  const double* __restrict__ alpha = alphab.p[blockIdx.z];
+  double* __restrict__ partial = partialb.p[blockIdx.z];
+  const int64_t N = Nv.v[blockIdx.z];
+  const double var = FSb.p[blockIdx.z][0];                    // the unit's kernel variance (F[0][0] of its hyper-parameter block)
   constexpr int ZL = 2 * 128 * LZ;
   constexpr int NW = 2 * WN;                                  // waves per workgroup
   constexpr int ZA = ZL + 4 * 128;                            // + alpha and sq of the tile's 128 rows and 128 columns
@@ -846,17 +907,21 @@ __global__ void RC_BOUNDS(WN) k_grad(const double* __restrict__ Linv, int64_t ld
 int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
   const int64_t T = h->Np / 128;
   const int64_t nb = T * (T + 1) / 2;
-  int rc = rc_ensure_partial(h, (size_t)nb * (h->M + 2));
+  int rc = rc_ensure_partial(h, (size_t)nb * (h->M + 2));      // (every unit of a batched call)
   if (rc) return rc;
   const double np = (double)h->Np;
-  RcProfScope ps(h, RC_K_GRAD, np * np * np / 3.0);
-  const unsigned grid = (unsigned)nb;
+  RC_BP(const double, Lb, h->Linv)
+  RC_BP(const double, Zb, h->Z)
+  RC_BP(const double, sb, h->sq)
+  RC_BP(const double, ab, h->alpha)
+  RC_BP(const double, Fb, h->FS_d)
+  RC_BP(double, pb, h->partial)
+  RcProfScope ps(h, RC_K_GRAD, (double)h->nb * np * np * np / 3.0);
+  const dim3 grid((unsigned)nb, 1, (unsigned)h->nb);
   if (h->M <= 32)
-    hipLaunchKernelGGL((k_grad<33, RC_WN>), dim3(grid), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
-                       h->sq, h->alpha, h->var, h->partial);
+    hipLaunchKernelGGL((k_grad<33, RC_WN>), grid, dim3(128 * RC_WN), 0, h->launch, Lb, h->Np, h->Np, rc_bn(h), h->M, Zb, sb, ab, Fb, pb);
   else
-    hipLaunchKernelGGL((k_grad<65, RC_WN>), dim3(grid), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
-                       h->sq, h->alpha, h->var, h->partial);
+    hipLaunchKernelGGL((k_grad<65, RC_WN>), grid, dim3(128 * RC_WN), 0, h->launch, Lb, h->Np, h->Np, rc_bn(h), h->M, Zb, sb, ab, Fb, pb);
   RC_HIP(hipGetLastError());
   *nrows = (int)nb;
   return 0;

@@ -12,8 +12,12 @@
 #define ZST 130   // LDS stride (doubles) between consecutive m of a Z panel: even (double2 alignment), bank-shift 4 per m
 
 // rows_per_block: rows sharing one lengthscale vector (the output block of a covariant GP; every row when there is one output)
-__global__ void k_scale(const double* __restrict__ X, const double* __restrict__ ell, double* __restrict__ Z, double* __restrict__ sq,
-                        int64_t rows, int M, int64_t rows_per_block) {
+__global__ void k_scale(RcBP<const double> Xb, RcBP<const double> ellb, RcBP<double> Zb, RcBP<double> sqb, int64_t rows, int M,
+                        int64_t rows_per_block) {
+  const double* __restrict__ X = Xb.p[blockIdx.z];
+  const double* __restrict__ ell = ellb.p[blockIdx.z];
+  double* __restrict__ Z = Zb.p[blockIdx.z];
+  double* __restrict__ sq = sqb.p[blockIdx.z];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   const double* el = ell + (i / rows_per_block) * M;
@@ -29,15 +33,20 @@ __global__ void k_scale(const double* __restrict__ X, const double* __restrict__
 // rows of new points scaled by the lengthscales of output `out`
 int rc_launch_scale_rows(rcgp_handle_s* h, const double* X, double* Z, double* sq, int64_t rows, int out) {
   RcProfScope ps(h, RC_K_MISC, 0.0);
-  hipLaunchKernelGGL(k_scale, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->launch, X, h->ell_d + (size_t)out * h->M, Z, sq, rows,
-                     h->M, rows > 0 ? rows : 1);
+  RcBP<const double> Xb = {{X}}, eb = {{h->ell_d + (size_t)out * h->M}};       // (new points: always one unit)
+  RcBP<double> Zb = {{Z}}, sb = {{sq}};
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->launch, Xb, eb, Zb, sb, rows, h->M, rows > 0 ? rows : 1);
   RC_HIP(hipGetLastError());
   return 0;
 }
 
 int rc_launch_scale(rcgp_handle_s* h) {
+  RC_BP(const double, Xb, h->X)
+  RC_BP(const double, eb, h->ell_d)
+  RC_BP(double, Zb, h->Z)
+  RC_BP(double, sb, h->sq)
   RcProfScope ps(h, RC_K_MISC, 0.0);
-  hipLaunchKernelGGL(k_scale, dim3((unsigned)((h->Np + 255) / 256)), dim3(256), 0, h->launch, h->X, h->ell_d, h->Z, h->sq, h->Np, h->M, h->Nb);
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)((h->Np + 255) / 256), 1, (unsigned)h->nb), dim3(256), 0, h->launch, Xb, eb, Zb, sb, h->Np, h->M, h->Nb);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -58,11 +67,20 @@ __device__ __forceinline__ void tri_decode_g(int64_t id, int& ti, int& tj) {
 // 512 threads per 128x128 tile, 32 outputs per thread (the C/D layout of 4 x 2 MFMA tiles per wave): <= 128 registers, so four
 // waves per SIMD are resident and the store phase of one wave overlaps the exp phase of the others.
 template <bool CROSS>
-__global__ void __launch_bounds__(512, 4) k_gram(double* __restrict__ out, int64_t ld, const double* __restrict__ Zr,
-                                                 const double* __restrict__ sqr, int64_t nr_valid, const double* __restrict__ Zc,
-                                                 const double* __restrict__ sqc, int64_t nc_valid, int M,
-                                                 const double* __restrict__ FS, int L, int tb, int rb) {
+__global__ void __launch_bounds__(512, 4) k_gram(RcBP<double> outb, int64_t ld, RcBP<const double> Zrb, RcBP<const double> sqrb, int64_t nr_cross,
+                                                 RcBP<const double> Zcb, RcBP<const double> sqcb, RcBN ncv, int M, RcBP<const double> FSb, int L,
+                                                 int tb, int rb) {
   extern __shared__ double sm[];
+  // the unit of this workgroup (blockIdx.z; a cross-Gram always has one). Valid rows: of the unit for the square Gram, the number of
+  // new points for a cross-Gram.
+  const int unit = CROSS ? 0 : blockIdx.z;
+  double* __restrict__ out = outb.p[unit];
+  const double* __restrict__ Zr = Zrb.p[unit];
+  const double* __restrict__ sqr = sqrb.p[unit];
+  const double* __restrict__ Zc = Zcb.p[unit];
+  const double* __restrict__ sqc = sqcb.p[unit];
+  const double* __restrict__ FS = FSb.p[unit];
+  const int64_t nc_valid = ncv.v[unit], nr_valid = CROSS ? nr_cross : nc_valid;
   const int Mp = (M + 3) & ~3;     // dimensions padded to a multiple of four (one fp64 MFMA consumes four), the padding zero
   double* zi = sm;                 // [Mp][ZST]
   double* zj = sm + Mp * ZST;      // [Mp][ZST]
@@ -178,9 +196,13 @@ int rc_launch_gram(rcgp_handle_s* h) {
   const size_t lds = gram_lds_bytes(h->M);
   RC_HIP(hipFuncSetAttribute((const void*)k_gram<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const double N = (double)h->N * (double)h->L;
-  RcProfScope ps(h, RC_K_GRAM, 8.0 * (N * (N + 1.0) / 2.0 + N * (double)h->M));   // algorithmic bytes
-  hipLaunchKernelGGL(k_gram<false>, dim3((unsigned)(T * (T + 1) / 2)), dim3(512), lds, h->launch, h->A, h->Np, h->Z, h->sq, h->N, h->Z,
-                     h->sq, h->N, h->M, h->FS_d, h->L, (int)(h->Nb / 128), 0);
+  RC_BP(double, Ab, h->A)
+  RC_BP(const double, Zb, h->Z)
+  RC_BP(const double, sb, h->sq)
+  RC_BP(const double, Fb, h->FS_d)
+  RcProfScope ps(h, RC_K_GRAM, (double)h->nb * 8.0 * (N * (N + 1.0) / 2.0 + N * (double)h->M));   // algorithmic bytes
+  hipLaunchKernelGGL(k_gram<false>, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)h->nb), dim3(512), lds, h->launch, Ab, h->Np, Zb, sb, (int64_t)0, Zb,
+                     sb, rc_bn(h), h->M, Fb, h->L, (int)(h->Nb / 128), 0);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -189,8 +211,12 @@ int rc_launch_cross_gram(rcgp_handle_s* h, int64_t n, int64_t np, int out) {
   const size_t lds = gram_lds_bytes(h->M);
   RC_HIP(hipFuncSetAttribute((const void*)k_gram<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   RcProfScope ps(h, RC_K_MISC, 0.0);
-  hipLaunchKernelGGL(k_gram<true>, dim3((unsigned)(h->Np / 128), (unsigned)(np / 128)), dim3(512), lds, h->launch, h->KsT, h->Np, h->Zs,
-                     h->sqs, n, h->Z, h->sq, h->N, h->M, h->FS_d, h->L, (int)(h->Nb / 128), out);
+  RcBP<double> Kb = {{h->KsT}};
+  RcBP<const double> Zsb = {{h->Zs}}, ssb = {{h->sqs}}, Zb = {{h->Z}}, sb = {{h->sq}}, Fb = {{h->FS_d}};
+  RcBN nv;
+  for (int u = 0; u < RC_MAX_BATCH; ++u) nv.v[u] = h->N;
+  hipLaunchKernelGGL(k_gram<true>, dim3((unsigned)(h->Np / 128), (unsigned)(np / 128)), dim3(512), lds, h->launch, Kb, h->Np, Zsb, ssb, n, Zb, sb, nv,
+                     h->M, Fb, h->L, (int)(h->Nb / 128), out);
   RC_HIP(hipGetLastError());
   return 0;
 }

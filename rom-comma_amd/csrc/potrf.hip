@@ -278,9 +278,14 @@ __device__ __forceinline__ void chol128_regs(double* S, double* Xd, double* rsd,
 
 // The diagonal kernel of the chain: factor the block at (j0, j0) in place, emit log L_ii, the eight 16x16 diagonal-block inverses (into the
 // diagonal blocks of invL, where k_trsm_subst and k_inv128_batched find them) and w_j = L_jj^-1 rhs_j (in place in rhs).
-__global__ void __launch_bounds__(512) k_diag_factor(double* __restrict__ A, int64_t ld, double* __restrict__ invL, double* __restrict__ rhs,
-                                                     double* __restrict__ logdiag, int* __restrict__ info, int64_t j0) {
+__global__ void __launch_bounds__(512) k_diag_factor(RcBP<double> Ab, int64_t ld, RcBP<double> invLb, RcBP<double> rhsb, RcBP<double> logdiagb,
+                                                     RcBP<int> infob, int64_t j0) {
   extern __shared__ double S[];
+  double* __restrict__ A = Ab.p[blockIdx.z];                      // one workgroup per unit of the batch
+  double* __restrict__ invL = invLb.p[blockIdx.z];
+  double* __restrict__ rhs = rhsb.p[blockIdx.z];
+  double* __restrict__ logdiag = logdiagb.p[blockIdx.z];
+  int* __restrict__ info = infob.p[blockIdx.z];
   double* Xd = S + 128 * LS;
   double* rsd = Xd + 8 * 16 * XS;
   double* rv = rsd + 128;
@@ -335,9 +340,12 @@ __device__ __forceinline__ double xval(const double* S, const double* Xd, int i,
 // A, its eight 16x16 diagonal-block inverses from invdiag). They are level 0 of the recursive-doubling inverse (rc_trtri); the
 // factorisation itself never needs them. Recursive doubling inside the block too (block sizes 16, 32, 64) on fp64 MFMA from LDS:
 // X21 = -C^-1 (B A^-1); the off-diagonal blocks of X live TRANSPOSED in the upper triangle of S.
-__global__ void __launch_bounds__(512) k_inv128_batched(const double* __restrict__ A, int64_t ld, const double* __restrict__ invdiag,
-                                                        double* __restrict__ W, int64_t ldw) {
+__global__ void __launch_bounds__(512) k_inv128_batched(RcBP<const double> Ab, int64_t ld, RcBP<const double> invdiagb, RcBP<double> Wb,
+                                                        int64_t ldw) {
   extern __shared__ double S[];
+  const double* __restrict__ A = Ab.p[blockIdx.z];
+  const double* __restrict__ invdiag = invdiagb.p[blockIdx.z];
+  double* __restrict__ W = Wb.p[blockIdx.z];
   double* Xd = S + 128 * LS;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -456,9 +464,11 @@ static int set_diag_attributes(rcgp_handle_s* h) {
 int rc_launch_inv128_batched(rcgp_handle_s* h) {
   int rc;
   if ((rc = set_diag_attributes(h))) return rc;
+  RC_BP(const double, Ab, h->A)
+  RC_BP(const double, ib, h->invdiag)
+  RC_BP(double, Wb, h->Linv)
   RcProfScope ps(h, RC_K_DIAG, 0.0, true);
-  RC_LAUNCH(k_inv128_batched, dim3((unsigned)(h->Np / 128)), dim3(512), RC_DIAG_LDS, (const double*)h->A, h->Np, (const double*)h->invdiag, h->Linv,
-            h->Np);
+  RC_LAUNCH(k_inv128_batched, dim3((unsigned)(h->Np / 128), 1, (unsigned)h->nb), dim3(512), RC_DIAG_LDS, Ab, h->Np, ib, Wb, h->Np);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -466,8 +476,13 @@ int rc_launch_inv128_batched(rcgp_handle_s* h) {
 int rc_launch_diag(rcgp_handle_s* h, int64_t j) {
   int rc;
   if ((rc = set_diag_attributes(h))) return rc;
-  RcProfScope ps(h, RC_K_DIAG, 128.0 * 128.0 * 128.0 / 3.0, true);
-  RC_LAUNCH(k_diag_factor, dim3(1), dim3(512), RC_DIAG_LDS, h->A, h->Np, h->invdiag + (j / 128) * 128 * 128, h->w, h->logdiag, h->info, j);
+  RC_BP(double, Ab, h->A)
+  RC_BP(double, ib, h->invdiag + (j / 128) * 128 * 128)
+  RC_BP(double, wb, h->w)
+  RC_BP(double, lb, h->logdiag)
+  RC_BP(int, fb, h->info)
+  RcProfScope ps(h, RC_K_DIAG, (double)h->nb * 128.0 * 128.0 * 128.0 / 3.0, true);
+  RC_LAUNCH(k_diag_factor, dim3(1, 1, (unsigned)h->nb), dim3(512), RC_DIAG_LDS, Ab, h->Np, ib, wb, lb, fb, j);
   RC_HIP(hipGetLastError());
   return 0;
 }
@@ -738,15 +753,24 @@ int rc_potrf(rcgp_handle_s* h) {
   h->launch = h->stream;
   h->launch_stop = nullptr;                                        // (an earlier call may have failed half-way)
   h->prof_pending = -1;
-  RC_HIP(hipMemcpyAsync(h->w, h->y, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  RC_HIP(hipMemsetAsync(h->info, 0, sizeof(int), h->stream));
+  for (int u = 0; u < h->nb; ++u) {                               // (every unit of a batched call; h alone otherwise)
+    rcgp_handle_s* hu = (h->nb > 1) ? h->bh[u] : h;
+    RC_HIP(hipMemcpyAsync(hu->w, hu->y, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    RC_HIP(hipMemsetAsync(hu->info, 0, sizeof(int), h->stream));
+    hu->gram_fresh = false;                                        // consumed, whatever happens below
+  }
   const bool la = h->lookahead && Np >= 4 * 128;                   // (the multi-stream schedule needs no minimum number of panels)
   h->la_cursor = 0;
-  h->gram_fresh = false;                                           // consumed, whatever happens below
+  auto mark_factored = [&]() {
+    for (int u = 0; u < h->nb; ++u) {
+      rcgp_handle_s* hu = (h->nb > 1) ? h->bh[u] : h;
+      hu->factored = true;
+      hu->inverted = false;
+    }
+  };
   if (la && h->fine_chain) {
     if ((rc = potrf_fine(h))) return rc;
-    h->factored = true;
-    h->inverted = false;
+    mark_factored();
     return 0;
   }
   if ((rc = panel_factor(h, 0, NB < Np ? NB : Np))) return rc;
@@ -786,7 +810,6 @@ int rc_potrf(rcgp_handle_s* h) {
       if ((rc = panel_factor(h, Jend, Jend2))) return rc;
     }
   }
-  h->factored = true;
-  h->inverted = false;
+  mark_factored();
   return 0;
 }

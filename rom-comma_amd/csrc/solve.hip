@@ -4,12 +4,48 @@
 #include "common.h"
 #include <string.h>
 
-int rc_ensure_partial(rcgp_handle_s* h, size_t elems) {
-  if (h->partial_elems >= elems) return 0;
-  if (h->partial) { RC_HIP(hipStreamSynchronize(h->stream)); RC_HIP(hipFree(h->partial)); h->partial = nullptr; }
-  RC_HIP(hipMalloc(&h->partial, elems * sizeof(double)));
-  h->partial_elems = elems;
+static int ensure_partial_one(rcgp_handle_s* h, rcgp_handle_s* hu, size_t elems) {
+  if (hu->partial_elems >= elems) return 0;
+  if (hu->partial) { RC_HIP(hipStreamSynchronize(h->stream)); RC_HIP(hipFree(hu->partial)); hu->partial = nullptr; hu->partial_elems = 0; }
+  RC_HIP(hipMalloc(&hu->partial, elems * sizeof(double)));
+  hu->partial_elems = elems;
   return 0;
+}
+
+// Room for `elems` doubles in the reduction scratch -- of every unit when h leads a batched call.
+int rc_ensure_partial(rcgp_handle_s* h, size_t elems) {
+  int rc;
+  for (int u = 0; u < h->nb; ++u)
+    if ((rc = ensure_partial_one(h, (h->nb > 1) ? h->bh[u] : h, elems))) return rc;
+  return 0;
+}
+
+// Per-unit pointer table of a launch led by h (common.h): the leader's buffer that contains `ptr`, the same offset in every unit's.
+int rc_bp_bytes(rcgp_handle_s* h, const void* ptr, void** out) {
+  struct Buf { double* rcgp_handle_s::*member; size_t bytes; };
+  const size_t np = (size_t)h->Np, d = sizeof(double);
+  const Buf bufs[] = {{&rcgp_handle_s::A, np * np * d},      {&rcgp_handle_s::Linv, np * np * d},  {&rcgp_handle_s::S, np * np * d},
+                      {&rcgp_handle_s::invdiag, np * 128 * d}, {&rcgp_handle_s::w, np * d},         {&rcgp_handle_s::logdiag, np * d},
+                      {&rcgp_handle_s::alpha, np * d},       {&rcgp_handle_s::sq, np * d},         {&rcgp_handle_s::y, np * d},
+                      {&rcgp_handle_s::Z, np * h->M * d},    {&rcgp_handle_s::X, np * h->M * d},   {&rcgp_handle_s::scal, RC_SCAL_ELEMS * d},
+                      {&rcgp_handle_s::partial, h->partial_elems * d},
+                      {&rcgp_handle_s::ell_d, ((size_t)h->L * h->M + (size_t)2 * h->L * h->L) * d}};
+  const char* p = static_cast<const char*>(ptr);
+  for (const Buf& b : bufs) {
+    const char* base = reinterpret_cast<const char*>(h->*(b.member));
+    if (!base || p < base || p >= base + b.bytes) continue;
+    const size_t off = (size_t)(p - base);
+    for (int u = 0; u < RC_MAX_BATCH; ++u) {
+      out[u] = nullptr;
+      if (u >= h->nb) continue;
+      char* ub = reinterpret_cast<char*>(h->bh[u]->*(b.member));
+      if (!ub) { h->err = "batched launch: a unit lacks a buffer the leader has"; return -8; }
+      out[u] = ub + off;
+    }
+    return 0;
+  }
+  h->err = "batched launch: pointer outside the leader's buffers";
+  return -8;
 }
 
 // L^-1 by recursive doubling. Level 0: the 128x128 inverses of the diagonal blocks, all in one launch (k_inv128_batched, potrf.hip).
@@ -19,12 +55,15 @@ int rc_ensure_partial(rcgp_handle_s* h, size_t elems) {
 int rc_trtri(rcgp_handle_s* h) {
   const int64_t Np = h->Np;
   int rc;
-  if (!h->Linv) {
-    RC_HIP(hipMalloc(&h->Linv, (size_t)Np * Np * sizeof(double)));
-    // the strictly upper 128-blocks are never written afterwards: zero once (readers may then run a k-range from a block boundary)
-    RC_HIP(hipMemsetAsync(h->Linv, 0, (size_t)Np * Np * sizeof(double), h->stream));
+  for (int u = 0; u < h->nb; ++u) {                               // (every unit of a batched call; h alone otherwise)
+    rcgp_handle_s* hu = (h->nb > 1) ? h->bh[u] : h;
+    if (!hu->Linv) {
+      RC_HIP(hipMalloc(&hu->Linv, (size_t)Np * Np * sizeof(double)));
+      // the strictly upper 128-blocks are never written afterwards: zero once (readers may then run a k-range from a block boundary)
+      RC_HIP(hipMemsetAsync(hu->Linv, 0, (size_t)Np * Np * sizeof(double), h->stream));
+    }
+    if (!hu->S) RC_HIP(hipMalloc(&hu->S, (size_t)Np * Np * sizeof(double)));
   }
-  if (!h->S) RC_HIP(hipMalloc(&h->S, (size_t)Np * Np * sizeof(double)));
   if ((rc = rc_launch_inv128_batched(h))) return rc;
   for (int64_t s = 128; s < Np; s *= 2) {
     const int total_pairs = (int)((Np - s + 2 * s - 1) / (2 * s));            // pairs with a non-empty C part: 2ps + s < Np
@@ -46,8 +85,11 @@ int rc_trtri(rcgp_handle_s* h) {
 }
 
 // partial[kc][j] = sum_{k in chunk kc, k >= tile start of j} Linv[k][j] * w[k]   (rows above the diagonal tile are never read)
-__global__ void __launch_bounds__(256) k_gemvT_partial(const double* __restrict__ Linv, int64_t ld, const double* __restrict__ w,
-                                                       int64_t Np, int rows_per_chunk, double* __restrict__ partial) {
+__global__ void __launch_bounds__(256) k_gemvT_partial(RcBP<const double> Linvb, int64_t ld, RcBP<const double> wb, int64_t Np, int rows_per_chunk,
+                                                       RcBP<double> partialb) {
+  const double* __restrict__ Linv = Linvb.p[blockIdx.z];
+  const double* __restrict__ w = wb.p[blockIdx.z];
+  double* __restrict__ partial = partialb.p[blockIdx.z];
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t k0c = (int64_t)blockIdx.y * rows_per_chunk;
   const int64_t k1 = (k0c + rows_per_chunk < Np) ? k0c + rows_per_chunk : Np;
@@ -78,7 +120,9 @@ __global__ void __launch_bounds__(256) k_gemvT_partial(const double* __restrict_
   }
 }
 
-__global__ void k_colreduce2(const double* __restrict__ partial, int64_t rows, int64_t n, double* __restrict__ out) {
+__global__ void k_colreduce2(RcBP<const double> partialb, int64_t rows, int64_t n, RcBP<double> outb) {
+  const double* __restrict__ partial = partialb.p[blockIdx.z];
+  double* __restrict__ out = outb.p[blockIdx.z];
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   double s = 0.0;
@@ -92,19 +136,28 @@ int rc_alpha(rcgp_handle_s* h) {
   const int64_t chunks = (Np + rows_per_chunk - 1) / rows_per_chunk;
   int rc = rc_ensure_partial(h, (size_t)chunks * Np);
   if (rc) return rc;
+  RC_BP(const double, Lb, h->Linv)
+  RC_BP(const double, wb, h->w)
+  RC_BP(double, pb, h->partial)
+  RC_BP(const double, pcb, (const double*)h->partial)
+  RC_BP(double, ab, h->alpha)
   RcProfScope ps(h, RC_K_MISC, 0.0);
-  hipLaunchKernelGGL(k_gemvT_partial, dim3((unsigned)((Np + 255) / 256), (unsigned)chunks), dim3(256), 0, h->stream, h->Linv, Np, h->w, Np,
-                     rows_per_chunk, h->partial);
+  hipLaunchKernelGGL(k_gemvT_partial, dim3((unsigned)((Np + 255) / 256), (unsigned)chunks, (unsigned)h->nb), dim3(256), 0, h->stream, Lb, Np, wb, Np,
+                     rows_per_chunk, pb);
   RC_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_colreduce2, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, h->stream, h->partial, chunks, Np, h->alpha);
+  hipLaunchKernelGGL(k_colreduce2, dim3((unsigned)((Np + 255) / 256), 1, (unsigned)h->nb), dim3(256), 0, h->stream, pcb, chunks, Np, ab);
   RC_HIP(hipGetLastError());
   return 0;
 }
 
 // Deterministic single-block reductions: out[0] = sum w^2, out[1] = sum logdiag.
-__global__ void __launch_bounds__(1024) k_lml_reduce(const double* __restrict__ w, const double* __restrict__ logdiag, int64_t n,
-                                                     double* __restrict__ out) {
+// With `gather` (a batched evaluation): the unit's whole result block -- these two sums, its gradient sums (already in scal[8 ...]) and its
+// Cholesky status word -- is copied into row blockIdx.z of the leader's result table, so that ONE copy brings every unit's numbers down.
+__global__ void __launch_bounds__(1024) k_lml_reduce(RcBP<const double> wb, RcBP<const double> logdiagb, int64_t n, RcBP<double> outb, double* gather) {
   __shared__ double sa[1024], sb[1024];
+  const double* __restrict__ w = wb.p[blockIdx.z];
+  const double* __restrict__ logdiag = logdiagb.p[blockIdx.z];
+  double* out = outb.p[blockIdx.z];
   double a = 0.0, b = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += 1024) {
     a = fma(w[i], w[i], a);
@@ -121,6 +174,11 @@ __global__ void __launch_bounds__(1024) k_lml_reduce(const double* __restrict__ 
     __syncthreads();
   }
   if (threadIdx.x == 0) { out[0] = sa[0]; out[1] = sb[0]; }
+  if (gather) {
+    double* g = gather + (size_t)blockIdx.z * RC_SCAL_ELEMS;
+    if (threadIdx.x == 0) { g[0] = sa[0]; g[1] = sb[0]; }
+    else if (threadIdx.x >= 2 && threadIdx.x <= RC_SCAL_INFO) g[threadIdx.x] = out[threadIdx.x];
+  }
 }
 
 // The numbers of one evaluation leave the device in ONE copy into pinned host memory behind ONE synchronisation: the two LML sums,
@@ -128,7 +186,9 @@ __global__ void __launch_bounds__(1024) k_lml_reduce(const double* __restrict__ 
 int rc_lml_value(rcgp_handle_s* h, double* lml) {
   {
     RcProfScope ps(h, RC_K_MISC, 0.0);
-    hipLaunchKernelGGL(k_lml_reduce, dim3(1), dim3(1024), 0, h->stream, h->w, h->logdiag, h->Np, h->scal);
+    RcBP<const double> wb = {{h->w}}, lb = {{h->logdiag}};
+    RcBP<double> ob = {{h->scal}};
+    hipLaunchKernelGGL(k_lml_reduce, dim3(1), dim3(1024), 0, h->stream, wb, lb, h->Np, ob, (double*)nullptr);
     RC_HIP(hipGetLastError());
   }
   double* host = h->pin + h->pin_result;
@@ -147,8 +207,10 @@ int rc_lml_value(rcgp_handle_s* h, double* lml) {
 }
 
 // out[c] = sum_r partial[r][c], one block per column, fixed-order tree.
-__global__ void __launch_bounds__(256) k_rowreduce(const double* __restrict__ partial, int64_t rows, int cols, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_rowreduce(RcBP<const double> partialb, int64_t rows, int cols, RcBP<double> outb) {
   __shared__ double sm[256];
+  const double* __restrict__ partial = partialb.p[blockIdx.z];
+  double* __restrict__ out = outb.p[blockIdx.z];
   const int c = blockIdx.x;
   double s = 0.0;
   for (int64_t r = threadIdx.x; r < rows; r += 256) s += partial[r * cols + c];
@@ -163,8 +225,21 @@ __global__ void __launch_bounds__(256) k_rowreduce(const double* __restrict__ pa
 
 // Queue the final reduction of the gradient partials (-> scal[8 ...]); rc_lml_value then brings them down with the LML sums.
 int rc_grad_queue(rcgp_handle_s* h, int nrows) {
+  RC_BP(const double, pb, (const double*)h->partial)
+  RC_BP(double, ob, h->scal + 8)
   RcProfScope ps(h, RC_K_MISC, 0.0);
-  hipLaunchKernelGGL(k_rowreduce, dim3((unsigned)(h->M + 2)), dim3(256), 0, h->stream, h->partial, (int64_t)nrows, h->M + 2, h->scal + 8);
+  hipLaunchKernelGGL(k_rowreduce, dim3((unsigned)(h->M + 2), 1, (unsigned)h->nb), dim3(256), 0, h->stream, pb, (int64_t)nrows, h->M + 2, ob);
+  RC_HIP(hipGetLastError());
+  return 0;
+}
+
+// Batched evaluation led by h: the two LML sums of every unit, and every unit's result block gathered into h->bres_d (k_lml_reduce).
+int rc_batch_lml_reduce(rcgp_handle_s* h) {
+  RC_BP(const double, wb, h->w)
+  RC_BP(const double, lb, h->logdiag)
+  RC_BP(double, ob, h->scal)
+  RcProfScope ps(h, RC_K_MISC, 0.0);
+  hipLaunchKernelGGL(k_lml_reduce, dim3(1, 1, (unsigned)h->nb), dim3(1024), 0, h->stream, wb, lb, h->Np, ob, h->bres_d);
   RC_HIP(hipGetLastError());
   return 0;
 }
