@@ -400,9 +400,10 @@ def _batch_failure(gps: Sequence[RcGP], rc: int, what: str):
 def lml_grad_batch(gps: Sequence[RcGP]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """LML and gradient of several units in ONE schedule on the GPU (``rcgp_lml_grad_batch``): (lml (n,), grad (n, M + 2),
     status (n,)); status[u] = k > 0 where unit u's matrix is not positive definite at leading minor k (its numbers are NaN)."""
+    handles = _handles(gps)                               # (checks the number of units)
     n, M = len(gps), gps[0].M
     lml, grad, status = np.empty(n), np.empty((n, M + 2)), np.zeros(n, dtype=np.int32)
-    rc = gps[0]._lib.rcgp_lml_grad_batch(n, _handles(gps), _dp(lml), _dp(grad), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    rc = gps[0]._lib.rcgp_lml_grad_batch(n, handles, _dp(lml), _dp(grad), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
     if rc != 0:
         _batch_failure(gps, rc, 'rcgp_lml_grad_batch')
     return lml, grad, status
@@ -410,8 +411,9 @@ def lml_grad_batch(gps: Sequence[RcGP]) -> Tuple[np.ndarray, np.ndarray, np.ndar
 
 def factor_batch(gps: Sequence[RcGP]) -> np.ndarray:
     """``rcgp_factor`` for several units in one schedule; returns the status word of every unit."""
+    handles = _handles(gps)
     status = np.zeros(len(gps), dtype=np.int32)
-    rc = gps[0]._lib.rcgp_factor_batch(len(gps), _handles(gps), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    rc = gps[0]._lib.rcgp_factor_batch(len(gps), handles, status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
     if rc != 0:
         _batch_failure(gps, rc, 'rcgp_factor_batch')
     return status

@@ -20,7 +20,7 @@ from romcomma_amd.base.classes import Data, Frame, Model
 from romcomma_amd.data.storage import Fold
 from romcomma_amd.data.storage import Frame as DataFrameCSV
 from romcomma_amd.gpr.kernels import Kernel
-from romcomma_amd.gpr.optimize import fit_lbfgsb, fit_lbfgsb_mo
+from romcomma_amd.gpr.optimize import fit_lbfgsb, fit_lbfgsb_batch, fit_lbfgsb_mo
 
 
 class Likelihood(Model):
@@ -240,10 +240,14 @@ class GPR(Model):
 class HipGP(GPR):
     """ARD-RBF GPs on one MI355X through librcgp.so.
 
-    Independent outputs: one device handle holds X (shared by the L outputs) and the N x N work matrices; the outputs are
-    fitted / queried in turn (``rcgp_set_y``), exactly as the reference loops ``for gp in self._implementation``
-    (gpr/models.py:360-361). To spread outputs or folds over GPUs, run one process per GPU and give each its share
-    (``romcomma_amd.user.run``).
+    Independent outputs: a POOL of device handles (units), each with its own copy of X and its own N x N work matrices. Output ``l``
+    lives on unit ``l mod P``; with P = L every output keeps its factor, L^-1 and alpha on the device between calls. Where the
+    reference loops ``for gp in self._implementation`` one output after the other (gpr/models.py:360-361), ``calibrate`` fits the
+    outputs of a pool-sized group AT ONCE: their L-BFGS-B runs advance in lockstep and every round of evaluations is one batched
+    schedule on the GPU (``rcgp_lml_grad_batch``) -- a single factorisation of the sizes the reference is run at cannot fill this chip.
+    Each output's fit is, to the last bit, the fit it would have had alone. ``units_per_gpu`` (argument, else the environment
+    variable RCGP_UNITS, else chosen from N) bounds P; P = 1 is the reference's one-after-the-other loop on one handle.
+    To spread outputs or folds over GPUs, run one process per GPU and give each its share (``romcomma_amd.user.run``).
 
     Covariant outputs (``is_covariant``): one (L N) x (L N) system, the reference's ``romcomma.gpf.models.MOGPR`` behind the
     covariant branches of gpr/models.py:335-338, 363-367, 377-379, 429-431 -- an ``rcgp_create_mo`` handle.
@@ -255,10 +259,14 @@ class HipGP(GPR):
         return {'maxiter': 5000, 'gtol': 1E-16}          # gpr/models.py:327-330
 
     def __init__(self, name: str, fold: Fold, is_read: bool | None, is_covariant: bool, is_isotropic: bool,
-                 kernel_parameters: Kernel.Data | None = None, likelihood_variance: np.ndarray | None = None, device: int | None = None):
+                 kernel_parameters: Kernel.Data | None = None, likelihood_variance: np.ndarray | None = None, device: int | None = None,
+                 units_per_gpu: int | None = None):
         self._is_covariant = bool(is_covariant)
         self._device = device
-        self._handle = None
+        self._units_per_gpu = units_per_gpu
+        self._units: Dict[int, _lib.RcGP] = {}            # pool slot -> device handle
+        self._unit_output: Dict[int, int] = {}             # pool slot -> the output whose y it holds
+        self._unit_signature: Dict[int, Any] = {}          # pool slot -> (output, hyper-parameters) current on the device
         self._cache: Dict[int, Dict[str, np.ndarray]] = {}
         self._is_isotropic = bool(is_isotropic)
         self._live_noise = None            # covariant GP: the full fitted likelihood covariance, from calibrate() until the next rebuild
@@ -276,21 +284,47 @@ class HipGP(GPR):
             self._device = int(os.environ.get('LOCAL_RANK', 0)) % max(_lib.device_count(), 1)
         return self._device
 
+    UNIT_MEMORY_BUDGET: float = 96.0e9     #: bytes of HBM the pool's N x N work matrices (three per unit) may take together
+
+    @property
+    def pool_size(self) -> int:
+        """P, the number of device handles the independent outputs are dealt to (1 for a covariant GP: one joint system)."""
+        if self._is_covariant:
+            return 1
+        if self._units_per_gpu is not None:
+            wanted = int(self._units_per_gpu)
+        else:
+            import os
+            wanted = int(os.environ.get('RCGP_UNITS', 0))
+        padded = -(-self._N // 128) * 128
+        if wanted <= 0:                                    # by size: what a batched evaluation was measured to gain (DESIGN.md section 4)
+            wanted = 8 if padded <= 4096 else (4 if padded <= 12288 else 2)
+        fits = int(self.UNIT_MEMORY_BUDGET // (3 * 8 * padded * padded))
+        return max(1, min(wanted, self._L, _lib.MAX_BATCH, fits))
+
+    def _unit(self, slot: int) -> _lib.RcGP:
+        """The device handle of pool slot ``slot`` (created on first use: X uploaded once per unit)."""
+        if slot not in self._units:
+            if self._is_covariant:
+                self._units[slot] = _lib.RcMOGP(self._X, self._Y, device=self.device)
+                self._unit_output[slot] = 0
+            else:
+                first = slot                               # the first output the slot serves
+                self._units[slot] = _lib.RcGP(self._X, self._Y[:, first], device=self.device)
+                self._unit_output[slot] = first
+        return self._units[slot]
+
     @property
     def handle(self) -> _lib.RcGP:
-        """The ``rcgp_handle`` (created on first use; X uploaded once)."""
-        if self._handle is None:
-            if self._is_covariant:
-                self._handle = _lib.RcMOGP(self._X, self._Y, device=self.device)
-            else:
-                self._handle = _lib.RcGP(self._X, self._Y[:, 0], device=self.device)
-            self._active_output = 0
-        return self._handle
+        """The device handle of pool slot 0 (the only one of a covariant GP, or with ``units_per_gpu = 1``)."""
+        return self._unit(0)
 
     def close(self):
-        if self._handle is not None:
-            self._handle.close()
-            self._handle = None
+        for unit in self._units.values():
+            unit.close()
+        self._units.clear()
+        self._unit_output.clear()
+        self._unit_signature.clear()
 
     def _hyper(self, l: int) -> Tuple[np.ndarray, float, float]:
         record = self._kernel.implementation[l]
@@ -316,28 +350,36 @@ class HipGP(GPR):
         gp = self.handle
         lengthscales, variance, noise = self._hyper_mo()
         signature = ('mo', lengthscales.tobytes(), variance.tobytes(), noise.tobytes())
-        if getattr(self, '_device_signature', None) != signature:
+        if self._unit_signature.get(0) != signature:
             gp.set_hyper(lengthscales, (variance + variance.T) / 2, noise)
-            self._device_signature = signature
+            self._unit_signature[0] = signature
+        return gp
+
+    def _load_output(self, slot: int, l: int) -> _lib.RcGP:
+        """Pool slot ``slot`` holding the targets of output ``l``."""
+        gp = self._unit(slot)
+        if self._unit_output[slot] != l:
+            gp.set_y(self._Y[:, l])
+            self._unit_output[slot] = l
+            self._unit_signature.pop(slot, None)
         return gp
 
     def _select(self, l: int) -> _lib.RcGP:
-        """Make output ``l`` with its stored hyper-parameters current on the device. Re-sending identical values is skipped so
-        the cached Cholesky factor / L^-1 / alpha on the device survive between K_inv_Y, predict and Sobol calls."""
-        gp = self.handle
+        """Make output ``l`` with its stored hyper-parameters current on its unit of the pool. Re-sending identical values is skipped
+        so the cached Cholesky factor / L^-1 / alpha on the device survive between K_inv_Y, predict and Sobol calls (with one unit
+        per output they survive for good)."""
+        slot = l % self.pool_size
+        gp = self._load_output(slot, l)
         lengthscales, variance, noise = self._hyper(l)
         signature = (l, tuple(lengthscales), variance, noise)
-        if getattr(self, '_device_signature', None) != signature:
-            if self._active_output != l:
-                gp.set_y(self._Y[:, l])
-                self._active_output = l
+        if self._unit_signature.get(slot) != signature:
             gp.set_hyper(lengthscales, variance, noise)
-            self._device_signature = signature
+            self._unit_signature[slot] = signature
         return gp
 
     @property
     def implementation(self) -> Tuple[Any, ...]:
-        """One (output index, hyper-parameter record) pair per independent output; the device handle is shared."""
+        """One (output index, hyper-parameter record) pair per independent output; the device handles are a pool (``pool_size``)."""
         if self._implementation is None:
             self._cache = {}
             self._implementation = tuple((l, record) for l, record in enumerate(self._kernel.implementation))   # one record if covariant
@@ -365,7 +407,7 @@ class HipGP(GPR):
         if self._is_covariant:
             # one optimisation over the Cholesky-parametrised (L,L) variances (gpr/models.py:359-367, gpf/base.py:32-96)
             lengthscales, variance, noise = self._hyper_mo()
-            self._device_signature = None
+            self._unit_signature.clear()
             fit = fit_lbfgsb_mo(gp, lengthscales, variance, noise, is_isotropic=self._is_isotropic,
                                 train_kernel_variance=bool(kernel_options['variance']),
                                 train_kernel_covariance=bool(kernel_options['covariance']),
@@ -381,17 +423,24 @@ class HipGP(GPR):
             self._reset_implementation()
             self._live_noise = np.array(fit['noise'], dtype=np.float64)        # the live model keeps its full Sigma (see _hyper_mo)
             return meta
-        fits = []
-        for l in range(self._L):
-            lengthscales, variance, noise = self._hyper(l)
-            if self._active_output != l:
-                gp.set_y(self._Y[:, l])
-                self._active_output = l
-            self._device_signature = None
-            fits.append(fit_lbfgsb(gp, lengthscales[0] if self._is_isotropic else lengthscales, variance, noise,
-                                   is_isotropic=self._is_isotropic, train_lengthscales=bool(kernel_options['lengthscales']['variant']),
-                                   train_variance=bool(kernel_options['variance']), train_noise=bool(likelihood_options['variance']),
-                                   method=method, **meta))
+        # The reference fits output after output (gpr/models.py:360-361). Here the outputs of one pool-sized group are fitted together: their
+        # L-BFGS-B runs in lockstep, each round of evaluations one batched schedule on the GPU (gpr/optimize.py::fit_lbfgsb_batch).
+        fits, pool = [], self.pool_size
+        common = dict(is_isotropic=self._is_isotropic, train_lengthscales=bool(kernel_options['lengthscales']['variant']),
+                      train_variance=bool(kernel_options['variance']), train_noise=bool(likelihood_options['variance']), method=method, **meta)
+        for first in range(0, self._L, pool):
+            outputs = range(first, min(first + pool, self._L))
+            units, starts = [], []
+            for l in outputs:
+                lengthscales, variance, noise = self._hyper(l)
+                units.append(self._load_output(l % pool, l))
+                self._unit_signature.pop(l % pool, None)
+                starts.append({'lengthscales': lengthscales[0] if self._is_isotropic else lengthscales, 'variance': variance, 'noise': noise})
+            group = fit_lbfgsb_batch(units, starts, **common)
+            for fit in group:
+                if isinstance(fit, Exception):             # as in the reference, a failing output fails the calibration
+                    raise fit
+            fits.extend(group)
         meta.update({'result': str(tuple(fit['result'] for fit in fits)), 'kernel': kernel_options, 'likelihood': likelihood_options})
         self.write_meta(meta)
         self._likelihood.data.replace(variance=np.array([[fit['noise'] for fit in fits]]),

@@ -9,7 +9,8 @@ chain rule stays on the host.
 """
 from __future__ import annotations
 
-from typing import Any, Dict, Optional
+import threading
+from typing import Any, Dict, Optional, Sequence
 
 import numpy as np
 import scipy.optimize
@@ -80,6 +81,136 @@ def fit_lbfgsb(gp, lengthscales, variance: float, noise: float, is_isotropic: bo
     log_marginal = gp.lml()
     return {'lengthscales': np.broadcast_to(ell, (M,)).copy(), 'variance': var, 'noise': nse, 'log_marginal': log_marginal,
             'result': result, 'nfev': state['nfev']}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Several units at once. The reference fits its outputs and folds one after the other (gpr/models.py:360-361, user/run.py:60-61); here the
+# units' optimisers advance in LOCKSTEP: one thread per unit runs the same SciPy routine as above, and their evaluations meet in one
+# ``rcgp_lml_grad_batch`` call -- one schedule on the GPU for all of them. Every unit sees exactly the numbers the single-handle call
+# would give it (the library guarantees that bit by bit), so each fit follows the path it would follow alone.
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _Lockstep:
+    """The meeting point of the units' optimiser threads. A thread hands in its point and sleeps; the thread that completes the round
+    (every live unit has handed one in) runs the batched evaluation for all of them and wakes the others. A unit whose fit has ended
+    leaves, and the rounds go on among the rest."""
+
+    def __init__(self, gps, batch_lml_grad, max_units: int):
+        self._gps, self._batch, self._max = list(gps), batch_lml_grad, int(max_units)
+        self._cond = threading.Condition()
+        self._live = set(range(len(self._gps)))
+        self._pending: Dict[int, tuple] = {}
+        self._done: Dict[int, Any] = {}
+        self.rounds = 0
+
+    def _run_round(self):                                   # (the condition's lock is held)
+        units = sorted(self._pending)
+        try:
+            for u in units:
+                self._gps[u].set_hyper(*self._pending[u])
+            for i in range(0, len(units), self._max):        # more live units than one call takes: several calls
+                part = units[i:i + self._max]
+                lml, grad, status = self._batch([self._gps[u] for u in part])
+                for k, u in enumerate(part):
+                    self._done[u] = (float(lml[k]), np.array(grad[k]), int(status[k]))
+        except Exception as failure:                         # a failed call fails every unit of the round
+            for u in units:
+                self._done.setdefault(u, failure)
+        self._pending.clear()
+        self.rounds += 1
+        self._cond.notify_all()
+
+    def evaluate(self, u: int, theta) -> tuple:
+        with self._cond:
+            self._pending[u] = theta
+            if set(self._pending) == self._live:
+                self._run_round()
+            else:
+                self._cond.wait_for(lambda: u in self._done)
+            out = self._done.pop(u)
+        if isinstance(out, Exception):
+            raise out
+        lml, grad, status = out
+        if status > 0:
+            from romcomma_amd._lib import NotPositiveDefiniteError
+            raise NotPositiveDefiniteError(status, f'rcgp_lml_grad_batch: matrix is not positive definite: leading minor {status}')
+        return lml, grad
+
+    def leave(self, u: int):
+        with self._cond:
+            self._live.discard(u)
+            self._pending.pop(u, None)
+            if self._pending and set(self._pending) == self._live:
+                self._run_round()
+
+    def alone(self, call):
+        """A single-handle library call made from a unit's thread: not while a round is in flight."""
+        with self._cond:
+            return call()
+
+
+class _LockstepUnit:
+    """What ``fit_lbfgsb`` sees of one unit: ``set_hyper`` only notes the point, ``lml_grad`` takes it to the meeting point."""
+
+    def __init__(self, lockstep: _Lockstep, u: int, gp):
+        self._lockstep, self._u, self._gp, self._theta = lockstep, u, gp, None
+        self.M = gp.M
+
+    def set_hyper(self, ell, variance, noise):
+        self._theta = (np.array(ell, dtype=np.float64), float(variance), float(noise))
+
+    def lml_grad(self):
+        return self._lockstep.evaluate(self._u, self._theta)
+
+    def lml(self):
+        def call():
+            self._gp.set_hyper(*self._theta)                  # normally the point of the last evaluation: nothing is recomputed
+            return self._gp.lml()
+        return self._lockstep.alone(call)
+
+
+def fit_lbfgsb_batch(gps: Sequence[Any], starts: Sequence[Dict[str, Any]], batch_lml_grad=None, max_units: Optional[int] = None,
+                     **common: Any) -> list:
+    """``fit_lbfgsb`` for several units (``romcomma_amd._lib.RcGP`` of one device, equal M and padded size) at once.
+
+    Args:
+        starts: per unit the keyword arguments of ``fit_lbfgsb`` that differ between units (lengthscales, variance, noise, ...).
+        common: keyword arguments shared by all units (is_isotropic, train_*, method, SciPy options).
+        batch_lml_grad: the batched evaluation, ``romcomma_amd._lib.lml_grad_batch`` by default.
+    Returns: per unit the dict ``fit_lbfgsb`` returns -- identical to what a fit of that unit alone returns -- or, for a unit whose
+        fit raised (e.g. a matrix that is not positive definite), the exception; the other units are not affected by it.
+    """
+    if len(gps) != len(starts):
+        raise ValueError('one start per unit')
+    if batch_lml_grad is None or max_units is None:
+        from romcomma_amd import _lib
+        batch_lml_grad = batch_lml_grad or _lib.lml_grad_batch
+        max_units = max_units or _lib.MAX_BATCH
+    if len(gps) == 1:                                         # nothing to meet with
+        try:
+            return [fit_lbfgsb(gps[0], **(dict(common) | dict(starts[0])))]
+        except Exception as failure:
+            return [failure]
+    lockstep = _Lockstep(gps, batch_lml_grad, max_units)
+    results: list = [None] * len(gps)
+
+    def run(u: int):
+        try:
+            results[u] = fit_lbfgsb(_LockstepUnit(lockstep, u, gps[u]), **(dict(common) | dict(starts[u])))
+        except BaseException as failure:                     # (the thread must leave the meeting point whatever happened)
+            results[u] = failure
+        finally:
+            lockstep.leave(u)
+
+    threads = [threading.Thread(target=run, args=(u,), name=f'rcgp-fit-{u}') for u in range(len(gps))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for r in results:
+        if isinstance(r, BaseException) and not isinstance(r, Exception):
+            raise r                                           # KeyboardInterrupt and the like
+    return results
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -80,7 +80,19 @@ class OracleGP:
         pass
 
 
+def lml_grad_batch(gps):
+    """Stand-in for ``_lib.lml_grad_batch``: the units one after the other (a matrix that is not positive definite gives status 1)."""
+    lml, grad, status = np.full(len(gps), np.nan), np.full((len(gps), gps[0].M + 2), np.nan), np.zeros(len(gps), dtype=np.int32)
+    for u, gp in enumerate(gps):
+        try:
+            lml[u], grad[u] = gp.lml_grad()
+        except np.linalg.LinAlgError:
+            status[u] = 1
+    return lml, grad, status
+
+
 def install():
     from romcomma_amd import _lib
     _lib.RcGP = OracleGP
+    _lib.lml_grad_batch = lml_grad_batch
     _lib.device_count = lambda: 1

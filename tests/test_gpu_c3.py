@@ -55,7 +55,7 @@ def test_c3_eight_outputs_on_one_design(gpu, tmp_path):
     np.testing.assert_allclose(Xf[order], X, rtol=1e-12, atol=1e-15)      # (through data.csv: pandas' float parser is good to an ulp)
     np.testing.assert_allclose(Yf[order], Y, rtol=1e-12, atol=1e-15)
 
-    # ---- per output: LML / gradient by properties and finite differences (the eight share one handle: set_y rotation)
+    # ---- per output: LML / gradient by properties and finite differences (the eight share a pool of four handles: set_y rotation)
     lml = gp.log_marginal_likelihood()
     assert lml.shape == (L,) and np.all(np.isfinite(lml))
     idx = np.random.default_rng(0).choice(N, 128, replace=False)
@@ -65,10 +65,10 @@ def test_c3_eight_outputs_on_one_design(gpu, tmp_path):
         np.testing.assert_allclose(mean_f[:, l], Yf[idx, l] - noise[0, l] * alpha[l, 0, idx], rtol=0, atol=2e-8 * np.max(np.abs(Yf[:, l])))
         assert np.all(sd_f[:, l] ** 2 <= noise[0, l] * 1.000001)
     assert np.all(gp.check_K_inv_Y(Xf[idx]) < 1e-8)
-    handle = gp.handle
+    assert gp.pool_size == 4 and gp.handle is gp._unit(0)     # N = 8192: four units, two outputs each (output l on unit l mod 4)
     for l in (0, 3, 7):
         h = gp._select(l)
-        assert h is handle                                    # one device handle serves all outputs
+        assert h is gp._unit(l % 4)
         value, grad = h.lml_grad()
         assert value == pytest.approx(lml[l], rel=1e-13)
         for p, step in ((2, 1e-5), (M, 1e-5), (M + 1, 1e-7)):
