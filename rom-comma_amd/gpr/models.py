@@ -237,6 +237,18 @@ class GPR(Model):
         self._implementation = self.implementation
 
 
+def default_units_per_gpu(N: int) -> int:
+    """How many equal-sized units one GPU is given at once when nobody says (argument ``units_per_gpu``, environment RCGP_UNITS): by
+    what a batched evaluation was measured to gain on an MI355X (a batch of 8 at N = 4096 runs 2.3x as many
+    evaluations per second as one unit at a time, a batch of 4 at N = 8192 1.25x, at N = 16384 the chip is full with one)."""
+    import os
+    wanted = int(os.environ.get('RCGP_UNITS', 0))
+    if wanted > 0:
+        return min(wanted, _lib.MAX_BATCH)
+    padded = -(-int(N) // 128) * 128
+    return 8 if padded <= 4096 else (4 if padded <= 12288 else 2)
+
+
 class HipGP(GPR):
     """ARD-RBF GPs on one MI355X through librcgp.so.
 
@@ -291,14 +303,8 @@ class HipGP(GPR):
         """P, the number of device handles the independent outputs are dealt to (1 for a covariant GP: one joint system)."""
         if self._is_covariant:
             return 1
-        if self._units_per_gpu is not None:
-            wanted = int(self._units_per_gpu)
-        else:
-            import os
-            wanted = int(os.environ.get('RCGP_UNITS', 0))
+        wanted = int(self._units_per_gpu) if self._units_per_gpu is not None else default_units_per_gpu(self._N)
         padded = -(-self._N // 128) * 128
-        if wanted <= 0:                                    # by size: what a batched evaluation was measured to gain (DESIGN.md section 4)
-            wanted = 8 if padded <= 4096 else (4 if padded <= 12288 else 2)
         fits = int(self.UNIT_MEMORY_BUDGET // (3 * 8 * padded * padded))
         return max(1, min(wanted, self._L, _lib.MAX_BATCH, fits))
 
@@ -398,11 +404,7 @@ class HipGP(GPR):
         """Fit the hyper-parameters of every output by L-BFGS-B on -LML and persist them: likelihood/variance.csv,
         likelihood/log_marginal.csv, kernel/variance.csv, kernel/lengthscales.csv and meta.json with the optimiser result
         (gpr/models.py:345-373)."""
-        meta = self.read_meta() if self._meta_json.exists() else self.META
-        kernel_options = self._kernel.calibrate(**(meta.pop('kernel', {}) | kwargs.pop('kernel', {})))
-        likelihood_options = self._likelihood.calibrate(**(meta.pop('likelihood', {}) | kwargs.pop('likelihood', {})))
-        meta.update(kwargs)
-        meta.pop('result', None)
+        meta, kernel_options, likelihood_options = self._calibration_options(kwargs)
         gp = self.handle
         if self._is_covariant:
             # one optimisation over the Cholesky-parametrised (L,L) variances (gpr/models.py:359-367, gpf/base.py:32-96)
@@ -426,21 +428,41 @@ class HipGP(GPR):
         # The reference fits output after output (gpr/models.py:360-361). Here the outputs of one pool-sized group are fitted together: their
         # L-BFGS-B runs in lockstep, each round of evaluations one batched schedule on the GPU (gpr/optimize.py::fit_lbfgsb_batch).
         fits, pool = [], self.pool_size
-        common = dict(is_isotropic=self._is_isotropic, train_lengthscales=bool(kernel_options['lengthscales']['variant']),
-                      train_variance=bool(kernel_options['variance']), train_noise=bool(likelihood_options['variance']), method=method, **meta)
+        common = self._fit_options(method, meta, kernel_options, likelihood_options)
         for first in range(0, self._L, pool):
-            outputs = range(first, min(first + pool, self._L))
-            units, starts = [], []
-            for l in outputs:
-                lengthscales, variance, noise = self._hyper(l)
-                units.append(self._load_output(l % pool, l))
-                self._unit_signature.pop(l % pool, None)
-                starts.append({'lengthscales': lengthscales[0] if self._is_isotropic else lengthscales, 'variance': variance, 'noise': noise})
+            units, starts = self._fit_units(range(first, min(first + pool, self._L)))
             group = fit_lbfgsb_batch(units, starts, **common)
             for fit in group:
                 if isinstance(fit, Exception):             # as in the reference, a failing output fails the calibration
                     raise fit
             fits.extend(group)
+        return self._store_fits(fits, meta, kernel_options, likelihood_options)
+
+    def _calibration_options(self, kwargs: Dict[str, Any]) -> Tuple[Dict[str, Any], Dict[str, Any], Dict[str, Any]]:
+        """(optimiser options, what the kernel trains, what the likelihood trains) for a ``calibrate(**kwargs)`` (gpr/models.py:345-358)."""
+        meta = self.read_meta() if self._meta_json.exists() else self.META
+        kernel_options = self._kernel.calibrate(**(meta.pop('kernel', {}) | kwargs.pop('kernel', {})))
+        likelihood_options = self._likelihood.calibrate(**(meta.pop('likelihood', {}) | kwargs.pop('likelihood', {})))
+        meta.update(kwargs)
+        meta.pop('result', None)
+        return meta, kernel_options, likelihood_options
+
+    def _fit_options(self, method: str, meta, kernel_options, likelihood_options) -> Dict[str, Any]:
+        return dict(is_isotropic=self._is_isotropic, train_lengthscales=bool(kernel_options['lengthscales']['variant']),
+                    train_variance=bool(kernel_options['variance']), train_noise=bool(likelihood_options['variance']), method=method, **meta)
+
+    def _fit_units(self, outputs) -> Tuple[list, list]:
+        """The pool's device handles loaded with ``outputs`` (at most ``pool_size`` of them, consecutive) and their start points."""
+        pool, units, starts = self.pool_size, [], []
+        for l in outputs:
+            lengthscales, variance, noise = self._hyper(l)
+            units.append(self._load_output(l % pool, l))
+            self._unit_signature.pop(l % pool, None)
+            starts.append({'lengthscales': lengthscales[0] if self._is_isotropic else lengthscales, 'variance': variance, 'noise': noise})
+        return units, starts
+
+    def _store_fits(self, fits, meta, kernel_options, likelihood_options) -> Dict[str, Any]:
+        """The side effects of MOGP.calibrate (gpr/models.py:362-372): meta.json with the optimiser results, the four parameter csv files."""
         meta.update({'result': str(tuple(fit['result'] for fit in fits)), 'kernel': kernel_options, 'likelihood': likelihood_options})
         self.write_meta(meta)
         self._likelihood.data.replace(variance=np.array([[fit['noise'] for fit in fits]]),
@@ -451,6 +473,53 @@ class HipGP(GPR):
         self._kernel._implementation = None
         self._reset_implementation()
         return meta
+
+    @classmethod
+    def calibrate_group(cls, gps: 'list[HipGP]', method: str = 'L-BFGS-B', **kwargs) -> list:
+        """``calibrate`` for several GPs AT ONCE on one GPU -- the folds of a cross-validation, which the reference fits one after the
+        other (user/run.py:60-61): every output of every GP is one unit, the units' L-BFGS-B runs advance in lockstep and each round of
+        evaluations is one batched schedule (``rcgp_lml_grad_batch``). Each GP ends with exactly the files ``calibrate`` alone gives it.
+        Returns per GP its ``meta`` dict or the exception that stopped it (the other GPs are not affected). GPs that cannot share a
+        batch (covariant; more outputs than pool slots; another padded size, M or device) are calibrated on their own, in turn."""
+        outcomes: list = [None] * len(gps)
+        groups: Dict[Any, list] = {}
+        for i, gp in enumerate(gps):
+            if gp._is_covariant or gp.pool_size < gp.L:
+                try:
+                    outcomes[i] = gp.calibrate(method=method, **dict(kwargs))
+                except Exception as failure:
+                    outcomes[i] = failure
+            else:
+                groups.setdefault((gp.device, -(-gp.N // 128), gp.M), []).append(i)
+        for members in groups.values():
+            per_call = max(1, _lib.MAX_BATCH // max(gps[i].L for i in members))
+            for first in range(0, len(members), per_call):
+                batch = members[first:first + per_call]
+                contexts, units, starts, owner = {}, [], [], []
+                for i in batch:
+                    gp = gps[i]
+                    try:
+                        options = gp._calibration_options(dict(kwargs))
+                        u, s = gp._fit_units(range(gp.L))
+                        common = gp._fit_options(method, *options)
+                    except Exception as failure:
+                        outcomes[i] = failure
+                        continue
+                    contexts[i] = options
+                    units += u
+                    starts += [common | start for start in s]     # (per GP: the stored meta.json may differ between folds)
+                    owner += [i] * len(u)
+                fits = fit_lbfgsb_batch(units, starts) if units else []
+                for i in contexts:
+                    mine = [fit for fit, o in zip(fits, owner) if o == i]
+                    failed = [fit for fit in mine if isinstance(fit, Exception)]
+                    try:
+                        if failed:
+                            raise failed[0]
+                        outcomes[i] = gps[i]._store_fits(mine, *contexts[i])
+                    except Exception as failure:
+                        outcomes[i] = failure
+        return outcomes
 
     def log_marginal_likelihood(self) -> np.ndarray:
         """(L,) log marginal likelihood at the stored hyper-parameters ((1,) for a covariant GP: one joint likelihood)."""

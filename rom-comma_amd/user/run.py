@@ -26,7 +26,7 @@ import numpy as np
 from romcomma_amd import dist
 from romcomma_amd.data.storage import Fold, Repository
 from romcomma_amd.gpr.kernels import Kernel
-from romcomma_amd.gpr.models import GPR, MOGP
+from romcomma_amd.gpr.models import GPR, MOGP, default_units_per_gpu
 from romcomma_amd.gsa.models import GSA, Sobol
 from romcomma_amd.user import contexts, results
 
@@ -79,13 +79,20 @@ def _my_folds(repo: Repository, shard_folds: bool = True) -> list[int]:
     return [every[i] for i in dist.shard_units(len(every), rank, world)] if (world > 1 and shard_folds) else every
 
 
-def _each_fold(repo: Repository, shard_folds: bool, job: Callable[[Fold], list]) -> list:
-    """``job(Fold)`` on this rank's folds; returns the last result. Sharded: all ranks agree on success before anyone goes on to the
-    barrier (a rank that failed would otherwise leave the rest waiting there until the RCCL timeout)."""
+def _each_fold(repo: Repository, shard_folds: bool, job: Callable[[Fold], list], group_job: Optional[Callable[[list], list]] = None,
+               at_once: int = 1) -> list:
+    """``job(Fold)`` on this rank's folds; returns the last result. With ``group_job`` and ``at_once`` > 1 the folds go to
+    ``group_job([Fold, ...])`` in groups of ``at_once`` instead (several folds fitted at once on one GPU). Sharded: all ranks agree on
+    success before anyone goes on to the barrier (a rank that failed would otherwise leave the rest waiting there until the RCCL timeout)."""
     outcome, caught = [], None
     try:
-        for k in _my_folds(repo, shard_folds):
-            outcome = job(Fold(repo, k))
+        mine = _my_folds(repo, shard_folds)
+        if group_job is not None and at_once > 1 and len(mine) > 1:
+            for first in range(0, len(mine), at_once):
+                outcome = group_job([Fold(repo, k) for k in mine[first:first + at_once]])
+        else:
+            for k in mine:
+                outcome = job(Fold(repo, k))
     except Exception as exception:
         caught = exception
     if shard_folds:
@@ -105,10 +112,16 @@ def _is_collector(shard_folds: bool) -> bool:
 
 def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | None, is_isotropic: bool | None,
         ignore_exceptions: bool = False, kernel_parameters: Kernel.Data | None = None, likelihood_variance: np.ndarray | None = None,
-        is_calibrated: bool = True, is_tested: bool = True, shard_folds: bool = True, **kwargs: Any) -> list[str]:
+        is_calibrated: bool = True, is_tested: bool = True, shard_folds: bool = True, units_per_gpu: Optional[int] = None,
+        **kwargs: Any) -> list[str]:
     """Fit (and test) GPs on a Fold, or on every fold of a Repository followed by the cross-fold csv collection. ``None`` for
     ``is_read`` / ``is_covariant`` / ``is_isotropic`` means warm start / both / both (module docstring). ``shard_folds=False`` keeps all
     folds on the calling rank (a rank that owns a whole ``Y.l`` repository, ``Y_splits_sharded``). Returns the model names, in plan order.
+
+    ``units_per_gpu`` (not in the reference, which walks its folds one after the other, user/run.py:60-61): how many (fold, output) units
+    this rank's GPU is given AT ONCE -- the independent GPs of that many folds are calibrated together, their L-BFGS-B runs in lockstep,
+    every round of evaluations one batched schedule on the device (``HipGP.calibrate_group``). Each fold ends with exactly the files it
+    gets alone. Default: RCGP_UNITS, else by the folds' size (``default_units_per_gpu``); 1 = one fold after the other.
     """
     plan = _plan(is_read, is_covariant, is_isotropic)
     names = [variant.model_name(name) for variant in plan]
@@ -120,7 +133,7 @@ def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | 
                 gp = None
                 try:
                     fresh = () if resume else (kernel_parameters, likelihood_variance)
-                    gp = MOGP(model_name, fold, resume, variant.covariant, variant.isotropic, *fresh)
+                    gp = MOGP(model_name, fold, resume, variant.covariant, variant.isotropic, *fresh, units_per_gpu=units_per_gpu)
                     if is_calibrated:
                         gp.calibrate(**kwargs)
                     if is_tested:
@@ -133,9 +146,46 @@ def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | 
                         gp.close()
         return names
 
+    def on_fold_group(folds: list[Fold]) -> list[str]:
+        """The plan, variant by variant, on several folds at once: construct the folds' GPs, calibrate them together, test each."""
+        for variant, model_name in zip(plan, names):
+            with contexts.Timer(f'folds {[fold.meta["k"] for fold in folds]} {model_name} GPR'):
+                gps: list = []
+                try:
+                    for fold in folds:
+                        try:
+                            resume = _resolve_warm_start(fold, name, variant) if variant.start is None else variant.start
+                            fresh = () if resume else (kernel_parameters, likelihood_variance)
+                            gps.append(MOGP(model_name, fold, resume, variant.covariant, variant.isotropic, *fresh, units_per_gpu=units_per_gpu))
+                        except Exception:
+                            if not ignore_exceptions:
+                                raise
+                    ready = gps
+                    if is_calibrated:
+                        outcomes = MOGP.calibrate_group(gps, **kwargs)
+                        failures = [outcome for outcome in outcomes if isinstance(outcome, Exception)]
+                        if failures and not ignore_exceptions:
+                            raise failures[0]
+                        ready = [gp for gp, outcome in zip(gps, outcomes) if not isinstance(outcome, Exception)]
+                    if is_tested:
+                        for gp in ready:
+                            try:
+                                gp.test()
+                            except Exception:
+                                if not ignore_exceptions:
+                                    raise
+                finally:
+                    for gp in gps:
+                        gp.close()
+        return names
+
     if isinstance(repo, Fold):
         return on_fold(repo)
-    _each_fold(repo, shard_folds, on_fold)
+    at_once = 1
+    if is_calibrated and len(repo.folds) > 1:
+        at_once = int(units_per_gpu) if units_per_gpu is not None else default_units_per_gpu(repo.N)
+        at_once = max(1, at_once // max(int(repo.L), 1))          # (every output of a fold is a unit of its own)
+    _each_fold(repo, shard_folds, on_fold, on_fold_group, at_once)
     if _is_collector(shard_folds):
         per_model = {
             '': ({'test': {'header': [0, 1]}, 'test_summary': {'header': [0, 1], 'index_col': 0}} if is_tested else {}),

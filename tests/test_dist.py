@@ -196,14 +196,14 @@ def test_gsa_outputs_with_eight_ranks_reproduces_the_single_process_tables(tmp_p
     import oracle_backend
     from romcomma_amd import _lib
     from romcomma_amd.user import run
-    keep = (_lib.RcGP, _lib.device_count)
+    keep = (_lib.RcGP, _lib.device_count, _lib.lml_grad_batch)
     oracle_backend.install()
     try:
         single = _eight_output_repo(tmp_path / 'single').into_K_folds(-2, seed=5)
         run.gpr('gpr', single, is_read=False, is_covariant=False, is_isotropic=False)
         run.gsa('gpr', single, is_covariant=False, is_isotropic=False)
     finally:
-        _lib.RcGP, _lib.device_count = keep
+        _lib.RcGP, _lib.device_count, _lib.lml_grad_batch = keep
     multi = _eight_output_repo(tmp_path / 'multi').into_K_folds(-2, seed=5)
     mp.spawn(_outputs_worker, args=(8, _free_port(), str(multi.folder), -1), nprocs=8, join=True)
     outcomes = [(multi.folder / f'outcome.{r}').read_text() for r in range(8)]
@@ -219,6 +219,36 @@ def test_gsa_outputs_with_eight_ranks_reproduces_the_single_process_tables(tmp_p
                 assert np.any(np.abs(b.values[cross]) > 1e-4), f'{rel}: the cross-output rows are empty'
     collected = pd.read_csv(multi.folder / 'gpr.v.a' / 'gsa' / 'closed' / 'S.csv')
     assert collected.shape[0] == 2 * 64 and sorted(collected['fold'].unique()) == [0, 1]
+
+
+def test_gpr_over_folds_at_once_writes_what_fold_after_fold_writes(tmp_path):
+    """``run.gpr(units_per_gpu=...)``: the reference walks the folds one after the other (user/run.py:60-61); with several folds per GPU
+    their GPs are calibrated together (HipGP.calibrate_group: lockstep L-BFGS-B, one batched evaluation per round). Host logic only
+    (device calls answered by the oracle): the isotropic -> anisotropic warm-start plan on five folds of two outputs, groups of 2 + 2 + 1
+    folds (four units per call), must leave byte-identical parameter and test files, fold by fold and collected."""
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import oracle_backend
+    from romcomma_amd import _lib
+    from romcomma_amd.user import run
+    keep = (_lib.RcGP, _lib.device_count, _lib.lml_grad_batch)
+    oracle_backend.install()
+    calls = []
+    batched = _lib.lml_grad_batch
+    _lib.lml_grad_batch = lambda gps: (calls.append(len(gps)), batched(gps))[1]
+    try:
+        repos = {}
+        for units in (1, 4):
+            repos[units] = _eight_output_repo(tmp_path / f'units{units}', N=60, L=2).into_K_folds(-5, seed=3)
+            names = run.gpr('gpr', repos[units], is_read=False, is_covariant=False, is_isotropic=None, units_per_gpu=units)
+            assert names == ['gpr.v.i', 'gpr.v.a']
+    finally:
+        _lib.RcGP, _lib.device_count, _lib.lml_grad_batch = keep
+    assert max(calls) == 4 and calls.count(4) > 20            # units = 1 makes no batched call; units = 4: two folds x two outputs per round,
+                                                              # fewer as units converge and leave
+    files = [f'{model}/{name}' for model in ('gpr.v.i', 'gpr.v.a') for name in
+             ('kernel/lengthscales.csv', 'kernel/variance.csv', 'likelihood/variance.csv', 'likelihood/log_marginal.csv', 'test.csv', 'test_summary.csv')]
+    for rel in [f'fold.{k}/{f}' for k in range(5) for f in files] + files:
+        assert (repos[1].folder / rel).read_bytes() == (repos[4].folder / rel).read_bytes(), rel
 
 
 def test_a_missing_model_on_one_rank_stops_all_eight_before_the_collectives(tmp_path):
