@@ -156,6 +156,12 @@ int rcgp_stage_potrf(rcgp_handle h);     /* blocked Cholesky in place + w = L^-1
 int rcgp_stage_trtri(rcgp_handle h);     /* L^-1 and alpha; requires rcgp_stage_potrf */
 int rcgp_sync(rcgp_handle h);
 
+/* Process-wide work counters since the library was loaded, in units (a batched call counts each of its units): which = 0 Cholesky
+ * factorisations, 1 inversions (L^-1 + alpha), 2 gradient evaluations, 3 batched rcgp_lml_grad_batch calls. For bench.py's count of the
+ * factorisations one drop-in run.gpr + run.gsa pass costs (the reference factors at least eight times besides its fit: gpr/models.py:365,
+ * 370, 439; gsa/calibrators.py:126-127 for each of three kinds). -1 for an unknown `which`. */
+int64_t rcgp_stat(int which);
+
 /* ---- profiling: HIP events around every kernel launch on the handle's stream ---- */
 enum { RCGP_K_GRAM = 0, RCGP_K_GEMM = 1, RCGP_K_DIAG = 2, RCGP_K_SOBOL = 3, RCGP_K_MISC = 4, RCGP_K_GRAD = 5, RCGP_K_COUNT = 6 };
 int rcgp_set_profiling(rcgp_handle h, int on);

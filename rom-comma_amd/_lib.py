@@ -51,6 +51,7 @@ SIGNATURES = {
     'rcgp_lml_grad_batch': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int)]),
     'rcgp_factor_batch': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
     'rcgp_stage_batch': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    'rcgp_stat': (ctypes.c_int64, [ctypes.c_int]),
     'rcgp_stage_gram': (ctypes.c_int, [ctypes.c_void_p]),
     'rcgp_stage_potrf': (ctypes.c_int, [ctypes.c_void_p]),
     'rcgp_stage_trtri': (ctypes.c_int, [ctypes.c_void_p]),
@@ -424,6 +425,12 @@ def stage_batch(stage: int, gps: Sequence[RcGP]):
     rc = gps[0]._lib.rcgp_stage_batch(int(stage), len(gps), _handles(gps))
     if rc != 0:
         _batch_failure(gps, rc, 'rcgp_stage_batch')
+
+
+def stat() -> dict:
+    """Process-wide work counters of the library (``rcgp_stat``), in units."""
+    lib = load()
+    return {name: int(lib.rcgp_stat(i)) for i, name in enumerate(('factorisations', 'inversions', 'gradients', 'batched_calls'))}
 
 
 def device_count() -> int:

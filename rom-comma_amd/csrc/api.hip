@@ -18,6 +18,9 @@ static const int64_t PRED_CAP = 4096;
 
 RC_API int rcgp_version(void) { return 100; }
 
+long long g_rc_stat[4] = {0, 0, 0, 0};
+RC_API int64_t rcgp_stat(int which) { return (which >= 0 && which < 4) ? (int64_t)g_rc_stat[which] : -1; }
+
 RC_API int rcgp_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return -1;
@@ -575,6 +578,7 @@ RC_API int rcgp_lml_grad_batch(int n, rcgp_handle* hs, double* lml, double* grad
   if ((rc = batch_check(n, hs, "rcgp_lml_grad_batch"))) return rc;
   if (!lml || !grad || !status) { hs[0]->err = "rcgp_lml_grad_batch: null argument"; return -2; }
   if ((rc = batch_ensure(n, hs, true))) return rc;
+  g_rc_stat[3] += 1;
   rcgp_handle_s* h = hs[0];
   std::vector<rcgp_handle_s*> units(hs, hs + n);
   {

@@ -278,6 +278,7 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
                          const int32_t* slices, double* phi_d, double* psi_d, double* phi_m, double* psi_m, int out_a = -1, int out_b = -1);
 
 // ---- util
+extern long long g_rc_stat[4];                               // process-wide counts (rcgp_stat): factorisations, inversions, gradient launches (units), batched calls
 int rc_ensure_pred(rcgp_handle_s* h);                        // predict / psi scratch (KsT, pvar, ...)
 int rc_ensure_partial(rcgp_handle_s* h, size_t elems);
 int rc_prof_collect(rcgp_handle_s* h);

@@ -910,6 +910,7 @@ int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
   int rc = rc_ensure_partial(h, (size_t)nb * (h->M + 2));      // (every unit of a batched call)
   if (rc) return rc;
   const double np = (double)h->Np;
+  g_rc_stat[2] += h->nb;
   RC_BP(const double, Lb, h->Linv)
   RC_BP(const double, Zb, h->Z)
   RC_BP(const double, sb, h->sq)

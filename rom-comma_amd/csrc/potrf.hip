@@ -759,6 +759,7 @@ int rc_potrf(rcgp_handle_s* h) {
     RC_HIP(hipMemsetAsync(hu->info, 0, sizeof(int), h->stream));
     hu->gram_fresh = false;                                        // consumed, whatever happens below
   }
+  g_rc_stat[0] += h->nb;
   const bool la = h->lookahead && Np >= 4 * 128;                   // (the multi-stream schedule needs no minimum number of panels)
   h->la_cursor = 0;
   auto mark_factored = [&]() {

@@ -55,6 +55,7 @@ int rc_bp_bytes(rcgp_handle_s* h, const void* ptr, void** out) {
 int rc_trtri(rcgp_handle_s* h) {
   const int64_t Np = h->Np;
   int rc;
+  g_rc_stat[1] += h->nb;
   for (int u = 0; u < h->nb; ++u) {                               // (every unit of a batched call; h alone otherwise)
     rcgp_handle_s* hu = (h->nb > 1) ? h->bh[u] : h;
     if (!hu->Linv) {

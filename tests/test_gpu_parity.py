@@ -434,16 +434,40 @@ def test_knobs_are_read_once_per_process(gpu, monkeypatch, capfd):
 def test_full_size_oracle_comparison(gpu, N, M):
     """The headline sizes against the oracle itself, not only through properties: LML and its gradient at the fixed benchmark
     hyper-parameters from ``rcgp_lml_grad`` and from ``oracle.lml_and_grad_blas`` (LAPACK potrf + potri and BLAS-3 sums
-    on the host cores: about 10 s and 25 s on the GPU box). 1e-8 on the LML, 1e-6 of the largest component on the gradient."""
+    on the host cores: about 10 s and 25 s on the GPU box). 1e-8 on the LML, 1e-6 of the largest component on the gradient; K_inv_Y, four
+    Sobol conditional variances and (at configs[1]) 512 predictions against the oracle as well."""
     X, y = o.synthetic_fold(N, M)
     ell, var, noise = o.bench_hyper(M)
     gp = gpu.RcGP(X, y)
     gp.set_hyper(ell, var, noise)
     lml, grad = gp.lml_grad()
+    # the second half of the headline metric at full size (round 4): the conditional variances of four slices -- first-order 0, closed
+    # [0, M/2), complement [M/2, M), full (gsa/calibrators.py:60-80, gsa/models.py:77-90) -- and, at BASELINE configs[1], predict on 512 of
+    # its o = 8192 new points (gpr/models.py:375-384)
+    slices = [(0, 1), (0, M // 2), (M // 2, M), (0, M)]
+    V = gp.sobol_closed(slices)
+    alpha_gpu = gp.k_inv_y()
+    if N == 8192:
+        Xs = o.synthetic_fold(8192, M, k=1)[0][::16]
+        mean, sd = gp.predict(Xs)
+        mean_f, sd_f = gp.predict(Xs, include_noise=False)
     gp.close()
     lml_ref, grad_ref = o.lml_and_grad_blas(X, y, ell, var, noise)
     assert lml == pytest.approx(lml_ref, rel=1e-8)
     assert np.max(np.abs(grad - grad_ref)) <= 1e-6 * np.max(np.abs(grad_ref))
+    alpha = o.k_inv_y(X, y, ell, var, noise)
+    assert relmax(alpha_gpu, alpha) < 1e-8
+    g, phi = o.sobol_prepare(X, alpha[None, :], np.array([var]), ell[None, :])
+    V_ref = o.sobol_V_pair(X, g[0], g[0], phi[0], phi[0], slices)             # the oracle's O(N^2) pair form over all rows: ~2 s per slice
+    np.testing.assert_allclose(V, V_ref, rtol=1e-8)
+    np.testing.assert_allclose(V[:3] / V[3], np.asarray(V_ref)[:3] / V_ref[3], rtol=0, atol=2e-8)      # the indices themselves (a ratio of two 1e-8 values)
+    if N == 8192:
+        rmean, rsd = o.predict(X, y, ell, var, noise, Xs)
+        rmean_f, rsd_f = o.predict(X, y, ell, var, noise, Xs, False)
+        np.testing.assert_allclose(mean, rmean, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(mean_f, rmean_f, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(sd, rsd, rtol=1e-6)
+        np.testing.assert_allclose(sd_f, rsd_f, rtol=1e-5, atol=1e-9)         # (var_f = k** - |L^-1 k*|^2 cancels to ~1e-3 of k**)
 
 
 def test_sobol_error_terms_many_dimensions(gpu):
