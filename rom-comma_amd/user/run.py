@@ -257,12 +257,19 @@ def _agreed_fold_table(first_split: Path) -> tuple[list[int], dict[int, tuple[in
     """Folds of the ``Y.l`` repositories and the (N, M) of each, as rank 0 sees them after everybody's fits are on disk, handed to every
     rank -- so that all ranks walk the same fold list even if their view of the shared folder lags."""
     rank, world, _ = dist.env_rank_world()
-    table = None
+    table, failure = None, None
     if rank == 0:
-        first = Repository(first_split, meta_only=True)
-        table = [(int(k), int(Fold(first, k).N), int(first.M)) for k in first.folds]
+        try:                                               # (fallible disk reads: their failure travels WITH the broadcast, so nobody waits in it)
+            first = Repository(first_split, meta_only=True)
+            table = [(int(k), int(Repository(first.fold_folder(k), meta_only=True).N), int(first.M)) for k in first.folds]
+        except Exception as exception:
+            failure = exception
     if dist.is_distributed():
-        table = dist.broadcast_object(table)
+        table, message = dist.broadcast_object((table, None if failure is None else f'{type(failure).__name__}: {failure}'))
+        if message is not None and failure is None:
+            failure = RuntimeError(f'rank 0 could not read the fold table of {first_split}: {message}')
+    if failure is not None:
+        raise failure
     return [k for k, _, _ in table], {k: (n, mm) for k, n, mm in table}
 
 

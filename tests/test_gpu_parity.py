@@ -359,39 +359,62 @@ def test_sobol_error_terms(gpu, L):
         gp.close()
 
 
-def _knob_case(env, case):
+_KNOB_FINGERPRINTS = {}
+
+
+@pytest.fixture(scope='module')
+def knob_reference_dir(tmp_path_factory):
+    """Where the first child process of a knob case leaves the oracle's reference values for the later ones (the oracle at
+    N = 9100 costs more than the GPU side of a case; once per case, not once per knob set)."""
+    return tmp_path_factory.mktemp('knob_reference')
+
+
+def _knob_case(env, case, reference_dir):
     """The schedule knobs are read once per process (the first rcgp_create), so every knob set runs in a process of its own:
-    tests/knob_case.py checks against the oracle there and prints one line. One at a time -- the GPU box limits concurrent processes."""
+    tests/knob_case.py checks against the oracle there and prints one line with a bit-level fingerprint of the GPU's numbers, which
+    must be THE SAME for every knob set of a case: the schedule decides when a tile is updated, never in which order its k-slabs are
+    added up. One child at a time -- the GPU box limits concurrent processes."""
     import os
     import subprocess
     import sys
-    full_env = {**os.environ, **env}
+    full_env = {**os.environ, **env, 'RCGP_KNOB_REF_DIR': str(reference_dir)}
     done = subprocess.run([sys.executable, str(Path(__file__).resolve().parent / 'knob_case.py'), case], env=full_env, capture_output=True,
-                          text=True, timeout=240)
-    assert done.returncode == 0 and done.stdout.strip().endswith('ok'), (env, done.stdout[-2000:], done.stderr[-2000:])
+                          text=True, timeout=280)
+    words = done.stdout.strip().split()
+    assert done.returncode == 0 and len(words) == 3 and words[:2] == [case, 'ok'], (env, done.stdout[-2000:], done.stderr[-2000:])
+    first_env, first = _KNOB_FINGERPRINTS.setdefault(case, (env, words[2]))
+    assert words[2] == first, f'{case}: {env} and {first_env} differ in the bits of their results'
 
 
-@pytest.mark.parametrize('env', [{'RCGP_LOOKAHEAD': '0'}, {'RCGP_FINE': '0'}, {'RCGP_NB': '256', 'RCGP_EXT': '1', 'RCGP_DEPTH': '1'},
-                                 {'RCGP_NB': '128', 'RCGP_EXT': '3', 'RCGP_DEPTH': '8'}, {'RCGP_NB': '384', 'RCGP_DEPTH': '2'},
-                                 {'RCGP_EXT': '6', 'RCGP_DEPTH': '1', 'RCGP_NB': '256'}, {'RCGP_EXT': '2'}])
-def test_tuning_knobs_do_not_change_results(gpu, env):
-    """Every run-time variant of the factorisation's schedule (sequential Cholesky, coarse panel chain, other panel widths / window
-    depths / chain extensions of the fine-grained Cholesky) is the same arithmetic up to rounding: LML, gradient and alpha against
-    the oracle at a size with a ragged last outer panel."""
-    _knob_case(env, 'evaluation')
+@pytest.mark.parametrize('env', [{}, {'RCGP_LOOKAHEAD': '0'}, {'RCGP_FINE': '0'}, {'RCGP_NB': '256', 'RCGP_EXT': '1', 'RCGP_DEPTH': '1', 'RCGP_TAIL': '0'},
+                                 {'RCGP_NB': '128', 'RCGP_EXT': '3', 'RCGP_DEPTH': '8', 'RCGP_TAIL': '0'},
+                                 {'RCGP_NB': '384', 'RCGP_DEPTH': '2', 'RCGP_TAIL': '4', 'RCGP_FARG': '3'},
+                                 {'RCGP_EXT': '6', 'RCGP_DEPTH': '1', 'RCGP_NB': '256', 'RCGP_TAIL': '0', 'RCGP_LEAN': '0', 'RCGP_FARG': '1'},
+                                 {'RCGP_EXT': '2', 'RCGP_FARG': '4', 'RCGP_LEAN': '5', 'RCGP_HALF_TILES': '0'}])
+def test_tuning_knobs_do_not_change_results(gpu, env, knob_reference_dir):
+    """Every run-time variant of the factorisation's schedule -- sequential Cholesky, coarse panel chain, and the fine-grained Cholesky
+    with other panel widths / window depths / chain extensions / tail lengths / far-update groups / lean thresholds -- is the same
+    arithmetic: LML, gradient and alpha against the oracle at N = 1700 (14 blocks; a ragged last outer panel), and the same BITS as the
+    default schedule. With the default tail (64 blocks) a matrix this small is all tail and NB / EXT / DEPTH have nothing to act on
+    (ADVICE r3): the sets that name them switch the tail off (RCGP_TAIL = 0: 7 and 14 outer panels) or shorten it to 4 blocks."""
+    _knob_case(env, 'evaluation', knob_reference_dir)
 
 
-@pytest.mark.parametrize('env', [{'RCGP_NB': '256', 'RCGP_DEPTH': '3'}, {'RCGP_EXT': '1', 'RCGP_DEPTH': '12'}])
-def test_fine_grained_cholesky_factor_many_panels_other_schedules(gpu, env):
-    _knob_case(env, 'factor')
+@pytest.mark.parametrize('env', [{}, {'RCGP_NB': '256', 'RCGP_DEPTH': '3', 'RCGP_TAIL': '0'}, {'RCGP_EXT': '1', 'RCGP_DEPTH': '12', 'RCGP_NB': '384', 'RCGP_TAIL': '8'}])
+def test_fine_grained_cholesky_factor_many_panels_other_schedules(gpu, env, knob_reference_dir):
+    """The factor itself, entry by entry against LAPACK, at N = 3400 (27 blocks) over 14 outer panels without a tail (a window three
+    panels deep: its last piece waits for the previous bulk kernel) and over 5 panels + an 8-block tail with a chain extension of one
+    block (the chain's stream waits for the previous panel's first window piece)."""
+    _knob_case(env, 'factor', knob_reference_dir)
 
 
-@pytest.mark.parametrize('env', [{'RCGP_NB': '512', 'RCGP_EXT': '1'}, {'RCGP_EXT': '2', 'RCGP_DEPTH': '1'}, {'RCGP_NB': '1536', 'RCGP_EXT': '6', 'RCGP_DEPTH': '3'}])
-def test_tuning_knobs_on_a_matrix_taller_than_the_tail(gpu, env):
-    """The knob sets again at N = 9100 (72 blocks): outer panels with window pieces and a bulk update in front of the 64-block tail, columns
-    taller than the split far update's threshold, a chain extension of one block (the next panel's first diagonal block then gets the last
-    column's update from a window piece)."""
-    _knob_case(env, 'tall')
+@pytest.mark.parametrize('env', [{}, {'RCGP_NB': '512', 'RCGP_EXT': '1'}, {'RCGP_EXT': '2', 'RCGP_DEPTH': '1', 'RCGP_TAIL': '16', 'RCGP_FARG': '3'},
+                                 {'RCGP_NB': '1536', 'RCGP_EXT': '6', 'RCGP_DEPTH': '3'}])
+def test_tuning_knobs_on_a_matrix_taller_than_the_tail(gpu, env, knob_reference_dir):
+    """The knob sets again at N = 9100 (72 blocks): outer panels with window pieces and a bulk update in front of the tail (64 blocks by
+    default, 16 in one set: 4 outer panels of 1024 first), columns taller than the split far update's threshold, far updates in groups of
+    three steps, a chain extension of one block (the next panel's first diagonal block then gets the last column's update from a window piece)."""
+    _knob_case(env, 'tall', knob_reference_dir)
 
 
 def test_fine_grained_cholesky_factor_many_panels(gpu):
