@@ -79,6 +79,9 @@ class OracleGP:
     def stage_potrf(self):
         pass
 
+    def stage_trtri(self):
+        pass
+
 
 def lml_grad_batch(gps):
     """Stand-in for ``_lib.lml_grad_batch``: the units one after the other (a matrix that is not positive definite gives status 1)."""
