@@ -766,6 +766,28 @@ int rc_launch_trtri_X(rcgp_handle_s* h, int64_t s, int pair0, int npairs) {
   return 0;
 }
 
+// Sum of v over the 64 lanes of a wave, the same value in every lane. Four butterfly steps inside each row of 16 lanes as DPP moves (VALU
+// speed: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- any pairing will do for a sum), then the four row sums by
+// v_readlane. The shuffle form (__shfl_xor = two ds_bpermute_b32 per step and a wait for each of six dependent steps) cost ~600 cycles per sum,
+// and the gradient epilogue needs 4 M + 2 of them per wave and tile: ~45 us per tile at M = 10 (round 3), of which this form leaves about half.
+// A fixed order, so results stay bit-reproducible from run to run.
+template <int CTRL>
+__device__ __forceinline__ double rc_dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rc_readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double rc_wave_sum(double v) {
+  v += rc_dpp_f64<0xB1>(v);
+  v += rc_dpp_f64<0x4E>(v);
+  v += rc_dpp_f64<0x141>(v);
+  v += rc_dpp_f64<0x140>(v);
+  return (rc_readlane_f64(v, 0) + rc_readlane_f64(v, 16)) + (rc_readlane_f64(v, 32) + rc_readlane_f64(v, 48));
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // K^-1 = L^-T L^-1 tile by tile, fused with the reduction for the LML gradient:
 //   Wij = alpha_i alpha_j - Kinv_ij ; G_m = sum Wij Kij (z_im - z_jm)^2 ; G_var = sum Wij Kij ; G_noise = tr W
@@ -819,11 +841,7 @@ __global__ void RC_BOUNDS(WN) k_grad(RcBP<const double> Linvb, int64_t ld, int64
     sj[ni] = ars[384 + wc_ + 16 * ni + fr_];
   }
   const int row0 = ti * 128, col0 = tj * 128;                 // (N < 2^31)
-  auto wave_sum = [](double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-  };
+  auto wave_sum = [](double v) { return rc_wave_sum(v); };
   if (lane_ < M) red[wave_ * (RC_MAX_M + 2) + lane_] = 0.0;    // this wave's M gradient sums, accumulated group by group (M <= 64 lanes)
   // One 16-row group (8 elements per lane) at a time, START TO END: its dot products in 8 registers, its eight W.K values, and at once
   // their M gradient sums (reduced over the wave and added into the wave's LDS slots by lane 0) -- so the group's accumulators are dead
@@ -982,11 +1000,7 @@ __global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t
     aj[ni] = ars[256 + wc_ + 16 * ni + fr_];
     sj[ni] = ars[384 + wc_ + 16 * ni + fr_];
   }
-  auto wave_sum = [](double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-  };
+  auto wave_sum = [](double v) { return rc_wave_sum(v); };
   for (int m = lane_; m < 2 * M; m += 64) red[wave_ * RW + m] = 0.0;   // this wave's 2M gradient sums, accumulated group by group
   // one 16-row group at a time, start to end, as in k_grad (its accumulators are dead when the next group starts: no scratch)
 #pragma unroll
