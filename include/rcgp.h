@@ -138,7 +138,7 @@ int rcgp_sobol_pair(rcgp_handle h, const double* phi_a, double pre_a, const doub
  * user/run.py:60-61, 132-133). A single factorisation of the sizes it is run at (benchmark_script.py:35-40: N <= 9840) cannot fill this
  * chip -- its chain of N/128 diagonal-block steps is latency-bound -- so these entries run ONE schedule over n handles (units): every
  * launch covers all units (the unit is blockIdx.z), the chains advance side by side, the update kernels of all units share the CUs.
- * Requirements: 1 <= n <= 8 distinct single-output handles of one device with equal M and equal padded size ceil(N / 128) (N itself may
+ * Requirements: 1 <= n <= 16 distinct single-output handles of one device with equal M and equal padded size ceil(N / 128) (N itself may
  * differ: folds of a K-fold split), hyper-parameters set on each. A unit's numbers are bit-identical to what the single-handle call
  * returns for it. Units whose factor (or L^-1) is still valid are not recomputed.
  * status[u] = 0, or k > 0 when unit u's matrix is not positive definite at leading minor k (its lml / grad entries are NaN, the other

@@ -385,7 +385,7 @@ def sobol_pair(gp: RcGP, phi_a, pre_a: float, alpha_a, shift_a: float, phi_b, pr
     return V
 
 
-MAX_BATCH = 8          # RC_MAX_BATCH of the library: units per batched call
+MAX_BATCH = 16         # RC_MAX_BATCH of the library: units per batched call
 
 
 def _handles(gps: Sequence[RcGP]):

@@ -30,7 +30,7 @@
 #define RC_LEAN_BLOCKS 40
 #endif
 #define RC_NB_OUTER 1024       // outer panel width of the blocked Cholesky (K of the trailing update)
-#define RC_MAX_BATCH 8         // most units (handles of equal padded size on one device) that one batched evaluation takes (rcgp_lml_grad_batch)
+#define RC_MAX_BATCH 16        // most units (handles of equal padded size on one device) that one batched evaluation takes (rcgp_lml_grad_batch)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -139,7 +139,7 @@ struct rcgp_handle_s {
   double prof_work[RC_K_COUNT] = {0, 0, 0, 0, 0, 0};   // algorithmic flops (GEMM) or bytes (Gram) or pair-terms (Sobol)
   // batch: the units a launch covers while this handle leads a batched call (api.hip: RcBatchScope). bh[0] == this.
   int nb = 1;
-  rcgp_handle_s* bh[RC_MAX_BATCH] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  rcgp_handle_s* bh[RC_MAX_BATCH] = {};
   double* bres_d = nullptr;    // RC_MAX_BATCH x RC_SCAL_ELEMS: the result blocks of a batched evaluation led by this handle (allocated on first use)
   double* bres_pin = nullptr;  // ... and their pinned host copy
   std::string err;

@@ -36,7 +36,7 @@ def set_all(ts):
 set_all(thetas)
 single = [gp.lml_grad() for gp in gps]
 identical = {}
-for nb in (1, 2, 3, 4, 8):
+for nb in (1, 2, 3, 4, 8, 16):
     if nb > U:
         continue
     set_all(other)
@@ -47,7 +47,7 @@ for nb in (1, 2, 3, 4, 8):
 
 # 2. wall time per batched evaluation (host included), alternating two points so that nothing is cached
 timing = {}
-for nb in (1, 2, 3, 4, 8):
+for nb in (1, 2, 3, 4, 8, 16):
     if nb > U:
         continue
     ms = []
