@@ -239,15 +239,15 @@ class GPR(Model):
 
 def default_units_per_gpu(N: int) -> int:
     """How many equal-sized units one GPU is given at once when nobody says (argument ``units_per_gpu``, environment RCGP_UNITS): by
-    what a batched evaluation was measured to gain on an MI355X (a batch of 8 at N = 4096 runs 2.3x as many
-    evaluations per second as one unit at a time, a batch of 4 at N = 8192 1.25x, two units at N = 16384 1.05x; at N <= 1024, where an
-    evaluation is a string of launch latencies, a batch costs little more than one unit)."""
+    what a batched evaluation was measured to gain on an MI355X (a batch of 16 at N = 4096 runs 2.6x as many
+    evaluations per second as one unit at a time (6x at N = 2048, 11x at N = 1024: there an evaluation is a string of launch latencies and
+    a batch costs little more than one unit), a batch of 4 at N = 8192 1.25x, two units at N = 16384 1.05x)."""
     import os
     wanted = int(os.environ.get('RCGP_UNITS', 0))
     if wanted > 0:
         return min(wanted, _lib.MAX_BATCH)
     padded = -(-int(N) // 128) * 128
-    return 16 if padded <= 1024 else (8 if padded <= 4096 else (4 if padded <= 12288 else 2))
+    return 16 if padded <= 4096 else (4 if padded <= 12288 else 2)
 
 
 class HipGP(GPR):

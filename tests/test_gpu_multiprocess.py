@@ -65,9 +65,9 @@ def test_two_ranks_shard_folds(gpu, tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
-    # rank 0 handled folds 0 and 2, rank 1 folds 1 and 3: the per-fold timers show it
-    assert 'fold.0 gpr.v.a GPR' in outs[0] and 'fold.2 gpr.v.a GPR' in outs[0] and 'fold.1 gpr.v.a GPR' not in outs[0]
-    assert 'fold.1 gpr.v.a GPR' in outs[1] and 'fold.3 gpr.v.a GPR' in outs[1]
+    # rank 0 handled folds 0 and 2 (fitted at once: units_per_gpu defaults to a group at this size), rank 1 folds 1 and 3: the timers show it
+    assert 'folds [0, 2] gpr.v.a GPR' in outs[0] and 'fold.0 gpr.v.a GSA' in outs[0] and 'fold.2 gpr.v.a GSA' in outs[0] and 'fold.1 ' not in outs[0]
+    assert 'folds [1, 3] gpr.v.a GPR' in outs[1] and 'fold.1 gpr.v.a GSA' in outs[1] and 'fold.3 gpr.v.a GSA' in outs[1]
     for rel in ('gpr.v.a/kernel/lengthscales.csv', 'gpr.v.a/likelihood/log_marginal.csv', 'gpr.v.a/gsa/closed/S.csv', 'gpr.v.a/test_summary.csv'):
         a = pd.read_csv(single.folder / rel)
         b = pd.read_csv(multi.folder / rel)
