@@ -104,10 +104,14 @@ class _Lockstep:
         self.rounds = 0
 
     def _run_round(self):                                   # (the condition's lock is held)
-        units = sorted(self._pending)
-        try:
-            for u in units:
+        units = []
+        for u in sorted(self._pending):                      # a point the library refuses (e.g. a lengthscale that underflowed to 0) fails ITS unit
+            try:
                 self._gps[u].set_hyper(*self._pending[u])
+                units.append(u)
+            except Exception as failure:
+                self._done[u] = failure
+        try:
             for i in range(0, len(units), self._max):        # more live units than one call takes: several calls
                 part = units[i:i + self._max]
                 lml, grad, status = self._batch([self._gps[u] for u in part])

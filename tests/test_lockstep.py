@@ -1,0 +1,83 @@
+"""Host logic of the lockstep fit driver (gpr/optimize.py::fit_lbfgsb_batch) on the CPU: the units' L-BFGS-B threads meet in one batched
+evaluation per round (the device calls are answered by the oracle here -- test infrastructure, never the product). What the reference
+does in its place: one gf.optimizers.Scipy().minimize per output, one after the other (gpr/models.py:359-361)."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as o
+from romcomma_amd.gpr.optimize import fit_lbfgsb, fit_lbfgsb_batch
+
+
+class Unit:
+    """The calls fit_lbfgsb makes on a handle, answered by the oracle."""
+
+    def __init__(self, X, y, refuse_after=None):
+        self.X, self.y, self.M, self.refuse_after, self.sets = X, y, X.shape[1], refuse_after, 0
+
+    def set_hyper(self, ell, variance, noise):
+        self.sets += 1
+        if self.refuse_after is not None and self.sets > self.refuse_after:
+            raise ValueError('refused')
+        self.theta = (np.array(ell), float(variance), float(noise))
+
+    def lml_grad(self):
+        return o.lml_and_grad(self.X, self.y, *self.theta)
+
+    def lml(self):
+        return o.lml(self.X, self.y, *self.theta)
+
+
+def batched(calls):
+    def call(gps):
+        calls.append(len(gps))
+        out = [gp.lml_grad() for gp in gps]
+        return np.array([a for a, _ in out]), np.array([b for _, b in out]), np.zeros(len(gps), dtype=np.int32)
+    return call
+
+
+START = dict(lengthscales=5.0 * np.ones(3), variance=2.0, noise=0.02)
+
+
+def test_lockstep_fits_equal_the_fits_alone_with_more_units_than_a_call_takes():
+    units = [Unit(*o.synthetic_fold(110 + 3 * k, 3, k=k)) for k in range(5)]
+    alone = [fit_lbfgsb(u, **START) for u in units]
+    calls = []
+    together = fit_lbfgsb_batch(units, [START] * 5, batch_lml_grad=batched(calls), max_units=2)
+    assert max(calls) == 2 and min(calls) == 1                 # five live units: calls of 2 + 2 + 1, fewer as units converge
+    for a, b in zip(alone, together):
+        assert a['nfev'] == b['nfev'] and a['log_marginal'] == b['log_marginal'] and np.array_equal(a['lengthscales'], b['lengthscales'])
+    assert len({a['nfev'] for a in alone}) > 1                 # the units leave at different rounds
+
+
+def test_a_point_the_library_refuses_fails_its_unit_only():
+    units = [Unit(*o.synthetic_fold(100, 3, k=k), refuse_after=(5 if k == 1 else None)) for k in range(3)]
+    out = fit_lbfgsb_batch(units, [START] * 3, batch_lml_grad=batched([]), max_units=8)
+    assert isinstance(out[1], ValueError) and isinstance(out[0], dict) and isinstance(out[2], dict)
+    alone = fit_lbfgsb(Unit(*o.synthetic_fold(100, 3, k=2)), **START)
+    assert out[2]['nfev'] == alone['nfev'] and out[2]['log_marginal'] == alone['log_marginal']
+
+
+def test_a_failed_batched_call_fails_the_units_of_its_round_and_nobody_hangs():
+    units = [Unit(*o.synthetic_fold(90, 3, k=k)) for k in range(3)]
+    state = {'n': 0}
+
+    def flaky(gps):
+        state['n'] += 1
+        if state['n'] == 4:
+            raise RuntimeError('device lost')
+        return batched([])(gps)
+    out = fit_lbfgsb_batch(units, [START] * 3, batch_lml_grad=flaky, max_units=8)
+    assert all(isinstance(r, RuntimeError) for r in out)
+
+
+def test_status_words_become_not_positive_definite_errors():
+    from romcomma_amd._lib import NotPositiveDefiniteError
+    units = [Unit(*o.synthetic_fold(80, 3, k=k)) for k in range(2)]
+
+    def second_unit_singular(gps):
+        lml, grad, status = batched([])(gps)
+        if len(gps) == 2:
+            status[1] = 17
+        return lml, grad, status
+    out = fit_lbfgsb_batch(units, [START] * 2, batch_lml_grad=second_unit_singular, max_units=8)
+    assert isinstance(out[1], NotPositiveDefiniteError) and out[1].k == 17 and isinstance(out[0], dict)
