@@ -67,11 +67,11 @@ def fold_schedule(rank, warmup, steps, n_folds, units=1):
 
 def pmc_traffic(N, M, kernel='k_grad'):
     """(HBM bytes per launch of `kernel`, the file they come from): the committed rocprofv3 --pmc passes of the same workload and build
-    (profiles/r03_pmc_c2.json, falling back to earlier rounds; produced by tools/pmc_summary.py with the gfx950 FETCH_SIZE correction).
+    (profiles/r04_pmc_c2.json, falling back to earlier rounds; produced by tools/pmc_summary.py with the gfx950 FETCH_SIZE correction).
     Counters cannot be read inside this process, so the number is NOT measured in this run; (None, None) for any other size."""
     if (N, M) != (16384, 10):
         return None, None
-    for name in ('r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'):
+    for name in ('r04_pmc_c2.json', 'r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'):
         path = ROOT / 'profiles' / name
         if path.exists():
             try:
@@ -470,7 +470,7 @@ def main():
                          'traffic_source': (f'{traffic_file}: rocprofv3 --pmc pass of the same workload and build, NOT measured in this run' if traffic_file else None),
                          'kernel': 'k_grad (K^-1 = L^-T L^-1 on fp64 MFMA fused with the LML-gradient reduction): the largest single launch, one per '
                                    'evaluation. By SUMMED time the K = NB update kernels of the Cholesky (k_gemm_nt_sub + k_syrk_lower, many launches on '
-                                   'several streams) are the larger family: stages.mfma_gemm_family, profiles/r03_*_kernel_stats.csv',
+                                   'several streams) are the larger family: stages.mfma_gemm_family, profiles/r04_*_kernel_stats.csv',
                          'launches': int(n_grad), 'avg_launch_ms': ms_grad / max(n_grad, 1),
                          'algorithmic_flops_per_launch': grad_flops / max(n_grad, 1),
                          'evaluation': {'algorithmic_flops': float(N) ** 3, 'ms': eval_ms, 'achieved': float(N) ** 3 / (eval_ms * 1e-3) / 1e12,
@@ -481,9 +481,8 @@ def main():
                 'gram': {'bound': 'hbm', 'achieved_GBs': gram_bytes / (ms_gram * 1e-3) / 1e9 if ms_gram > 0 else 0.0, 'peak_GBs': HBM_PEAK_GBS,
                          'frac': (gram_bytes / (ms_gram * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_gram > 0 else 0.0,
                          'launches': int(n_gram), 'avg_launch_ms': ms_gram / max(n_gram, 1),
-                         'timing': 'HIP events around the launches of the sampled evaluations in this run (an event pair brackets ~15-20 us more than the '
-                                   'kernel runs: at N = 8192 a 60 us launch reads as 78); the rocprofv3 --kernel-trace duration of the same kernel is in '
-                                   'profiles/*_kernel_stats.csv'},
+                         'timing': 'HIP events riding on the dispatches of the sampled evaluations in this run (hipExtLaunchKernelGGL start / stop events: '
+                                   'kernel begin to kernel end); the rocprofv3 --kernel-trace duration of the same kernel is in profiles/*_one_eval_c2_kernel_stats.csv'},
                 'cholesky': {'bound': 'mfma', 'algorithmic_flops': N ** 3 / 3.0, 'ms': min(chol_ms), 'achieved_TFLOPs': N ** 3 / 3.0 / (min(chol_ms) * 1e-3) / 1e12,
                              'frac': N ** 3 / 3.0 / (min(chol_ms) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                              'note': 'stand-alone rcgp_stage_potrf (incl. w = L^-1 y) after the timed region, best of 3, host wall clock around a sync'},
