@@ -226,3 +226,30 @@ def test_calibrate_fits_the_outputs_at_once_or_in_turn_alike(gpu, tmp_path):
         assert np.array_equal(fa[name], fb[name]), name
     assert np.array_equal(ka, kb)
     assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+
+
+def test_run_gpr_over_folds_at_once_writes_what_fold_after_fold_writes(gpu, tmp_path):
+    """``run.gpr(units_per_gpu=4)`` on the device: the four folds of a split are calibrated together (HipGP.calibrate_group -> lockstep
+    L-BFGS-B -> rcgp_lml_grad_batch; the folds' N differ by one row under one padded size) and tested; every parameter and test file, per
+    fold and collected, equals byte for byte what the reference's order -- fold after fold (user/run.py:60-61) -- leaves. The isotropic ->
+    anisotropic warm start runs through both."""
+    import pandas as pd
+    from romcomma_amd.data.storage import Repository
+    from romcomma_amd.user import run
+    rng = np.random.default_rng(4)
+    U = rng.random((1001, 3))
+    y = np.sin(2 * np.pi * U[:, 0]) + 0.6 * U[:, 1] ** 2 + 0.1 * U[:, 2] + 0.05 * rng.standard_normal(1001)
+    columns = pd.MultiIndex.from_tuples([('X', f'X.{m}') for m in range(3)] + [('Y', 'Y.0')])
+    table = pd.DataFrame(np.concatenate([U, y[:, None]], axis=1), columns=columns)
+    repos = {}
+    before = gpu.stat()['batched_calls']
+    for units in (1, 4):
+        repos[units] = Repository.from_df(tmp_path / f'units{units}', table).into_K_folds(-4, seed=2)
+        assert run.gpr('gpr', repos[units], is_read=False, is_covariant=False, is_isotropic=None, units_per_gpu=units) == ['gpr.v.i', 'gpr.v.a']
+        if units == 1:
+            assert gpu.stat()['batched_calls'] == before           # one fold after the other: no batched call
+    assert gpu.stat()['batched_calls'] > before + 20
+    files = [f'{model}/{name}' for model in ('gpr.v.i', 'gpr.v.a') for name in
+             ('kernel/lengthscales.csv', 'kernel/variance.csv', 'likelihood/variance.csv', 'likelihood/log_marginal.csv', 'test.csv', 'test_summary.csv')]
+    for rel in [f'fold.{k}/{f}' for k in range(4) for f in files] + files:
+        assert (repos[1].folder / rel).read_bytes() == (repos[4].folder / rel).read_bytes(), rel
