@@ -34,6 +34,56 @@ def sigmoid(u):
     return scipy.special.expit(np.asarray(u, dtype=np.float64))
 
 
+class _FitProblem:
+    """The optimisation problem of one independent-output GP as GPflow poses it (module docstring): the packed unconstrained vector,
+    which of its entries train, the map to the constrained hyper-parameters and the chain rule back. Shared by ``fit_lbfgsb`` (SciPy
+    drives it) and the reverse-communication driver of ``fit_lbfgsb_batch``."""
+
+    def __init__(self, M: int, lengthscales, variance: float, noise: float, is_isotropic: bool, train_lengthscales: bool,
+                 train_variance: bool, train_noise: bool):
+        self.M, self.is_isotropic = M, is_isotropic
+        ell0 = np.broadcast_to(np.asarray(lengthscales, dtype=np.float64).reshape(-1), (1,) if is_isotropic else (M,)).copy()
+        variance = max(float(variance), KERNEL_VARIANCE_FLOOR)
+        noise = max(float(noise), LIKELIHOOD_VARIANCE_FLOOR)
+        self.n_ell = ell0.shape[0]
+        self.u_all = np.concatenate([inv_softplus(ell0), [inv_softplus(variance)], [inv_softplus(noise - LIKELIHOOD_LOWER)]])
+        self.mask = np.array([train_lengthscales] * self.n_ell + [train_variance, train_noise])
+        self.nfev = 0
+
+    @property
+    def x0(self) -> np.ndarray:
+        return self.u_all[self.mask]
+
+    def unpack(self, u_train):
+        """(u, lengthscales (n_ell,), variance, noise) at the trainable values ``u_train``."""
+        u, n_ell = self.u_all.copy(), self.n_ell
+        u[self.mask] = u_train
+        return u, softplus(u[:n_ell]), float(softplus(u[n_ell])), float(LIKELIHOOD_LOWER + softplus(u[n_ell + 1]))
+
+    def theta(self, u_train):
+        """(u, (lengthscales (M,), variance, noise)): what ``set_hyper`` takes."""
+        u, ell, var, nse = self.unpack(u_train)
+        return u, (np.broadcast_to(ell, (self.M,)), var, nse)
+
+    def loss_and_gradient(self, u, lml: float, grad: np.ndarray):
+        """(-LML, its gradient w.r.t. the trainable unconstrained entries) from the library's LML and constrained-space gradient."""
+        M = self.M
+        self.nfev += 1
+        g_ell = np.array([np.sum(grad[:M])]) if self.is_isotropic else grad[:M]
+        g = np.concatenate([g_ell, grad[M:]]) * sigmoid(u)
+        return -lml, -g[self.mask]
+
+    def finish(self, gp, result) -> Dict[str, Any]:
+        """Set the optimum on the handle (normally the point of the last evaluation: nothing is recomputed) and report the fit."""
+        if result is not None:
+            self.u_all[self.mask] = result.x
+        _, ell, var, nse = self.unpack(self.u_all[self.mask])
+        gp.set_hyper(np.broadcast_to(ell, (self.M,)), var, nse)
+        log_marginal = gp.lml()
+        return {'lengthscales': np.broadcast_to(ell, (self.M,)).copy(), 'variance': var, 'noise': nse, 'log_marginal': log_marginal,
+                'result': result, 'nfev': self.nfev}
+
+
 def fit_lbfgsb(gp, lengthscales, variance: float, noise: float, is_isotropic: bool = False, train_lengthscales: bool = True,
                train_variance: bool = True, train_noise: bool = True, method: str = 'L-BFGS-B', callback=None,
                **options: Any) -> Dict[str, Any]:
@@ -47,40 +97,19 @@ def fit_lbfgsb(gp, lengthscales, variance: float, noise: float, is_isotropic: bo
         options: SciPy options, reference defaults maxiter=5000, gtol=1e-16 (gpr/models.py:327-330).
     Returns: dict(lengthscales (M,), variance, noise, log_marginal, result (scipy OptimizeResult), nfev).
     """
-    M = gp.M
-    ell0 = np.broadcast_to(np.asarray(lengthscales, dtype=np.float64).reshape(-1), (1,) if is_isotropic else (M,)).copy()
-    variance = max(float(variance), KERNEL_VARIANCE_FLOOR)
-    noise = max(float(noise), LIKELIHOOD_VARIANCE_FLOOR)
-    n_ell = ell0.shape[0]
-    u_all = np.concatenate([inv_softplus(ell0), [inv_softplus(variance)], [inv_softplus(noise - LIKELIHOOD_LOWER)]])
-    mask = np.array([train_lengthscales] * n_ell + [train_variance, train_noise])
-    state = {'nfev': 0}
-
-    def unpack(u_train):
-        u = u_all.copy()
-        u[mask] = u_train
-        return u, softplus(u[:n_ell]), float(softplus(u[n_ell])), float(LIKELIHOOD_LOWER + softplus(u[n_ell + 1]))
+    problem = _FitProblem(gp.M, lengthscales, variance, noise, is_isotropic, train_lengthscales, train_variance, train_noise)
 
     def objective(u_train):
-        u, ell, var, nse = unpack(u_train)
-        gp.set_hyper(np.broadcast_to(ell, (M,)), var, nse)
+        u, theta = problem.theta(u_train)
+        gp.set_hyper(*theta)
         lml, grad = gp.lml_grad()
-        state['nfev'] += 1
-        g_ell = np.array([np.sum(grad[:M])]) if is_isotropic else grad[:M]
-        g = np.concatenate([g_ell, grad[M:]]) * sigmoid(u)
-        return -lml, -g[mask]
+        return problem.loss_and_gradient(u, lml, grad)
 
     opts = {'maxiter': 5000, 'gtol': 1e-16} | options
-    if np.any(mask):
-        result = scipy.optimize.minimize(objective, u_all[mask], jac=True, method=method, options=opts, callback=callback)
-        u_all[mask] = result.x
-    else:
-        result = None
-    _, ell, var, nse = unpack(u_all[mask])
-    gp.set_hyper(np.broadcast_to(ell, (M,)), var, nse)
-    log_marginal = gp.lml()
-    return {'lengthscales': np.broadcast_to(ell, (M,)).copy(), 'variance': var, 'noise': nse, 'log_marginal': log_marginal,
-            'result': result, 'nfev': state['nfev']}
+    result = None
+    if np.any(problem.mask):
+        result = scipy.optimize.minimize(objective, problem.x0, jac=True, method=method, options=opts, callback=callback)
+    return problem.finish(gp, result)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -173,14 +202,173 @@ class _LockstepUnit:
         return self._lockstep.alone(call)
 
 
+# ---- the same lockstep without threads: SciPy's L-BFGS-B core by reverse communication ----------------------------------------------
+# scipy.optimize.minimize(method='L-BFGS-B') is a Python loop around the compiled routine ``setulb``, which RETURNS whenever it wants the
+# objective at a point (scipy/optimize/_lbfgsb_py.py::_minimize_lbfgsb). Driving that routine directly, one state per unit, lets ONE thread
+# advance every unit to its next request and answer all requests with one batched evaluation: the arithmetic -- hence every iterate, count
+# and message -- is that of ``minimize``, but a round of 16 small units costs the host ~0.15 ms instead of ~1 ms of sixteen threads
+# taking turns under the GIL. ``setulb`` is private to SciPy: the driver is used only where ``_RC_SELF_CHECK`` -- a
+# small fit run both ways, bit for bit, the first time it is needed -- has passed on the installed SciPy; otherwise the threads above run.
+
+_RC_OPTIONS = {'maxiter', 'gtol', 'ftol', 'maxcor', 'maxfun', 'maxls'}       # options this driver honours exactly as _minimize_lbfgsb does
+_RC_STATE = {'checked': False, 'ok': False}
+
+
+class _SetulbRun:
+    """One unit's L-BFGS-B run: the work arrays of ``_minimize_lbfgsb`` and its loop, cut at the point where the objective is wanted."""
+
+    def __init__(self, x0, maxiter=15000, gtol=1e-5, ftol=2.2204460492503131e-09, maxcor=10, maxfun=15000, maxls=20):
+        from scipy.optimize import _lbfgsb_py
+        self._py = _lbfgsb_py
+        if not maxls > 0:
+            raise ValueError('maxls must be positive.')
+        self.m, self.maxiter, self.maxfun, self.maxls = int(maxcor), maxiter, maxfun, int(maxls)
+        self.pgtol, self.factr = gtol, ftol / np.finfo(float).eps
+        x0 = np.asarray(x0).ravel()
+        n, m = x0.shape[0], self.m
+        self.n = n
+        self.nbd, self.low, self.up = np.zeros(n, np.int32), np.zeros(n, np.float64), np.zeros(n, np.float64)
+        self.x = np.array(x0, dtype=np.float64)
+        self.f, self.g = np.array(0.0, dtype=np.int32), np.zeros((n,), dtype=np.int32)
+        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+        self.iwa = np.zeros(3 * n, dtype=np.int32)
+        self.task, self.ln_task = np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.int32)
+        self.lsave, self.isave, self.dsave = np.zeros(4, dtype=np.int32), np.zeros(44, dtype=np.int32), np.zeros(29, dtype=np.float64)
+        self.nit, self.nfev, self.done = 0, 0, False
+        self._cached = None                                   # ScalarFunction evaluates at x0 on construction and serves the first request from it
+
+    def advance(self) -> bool:
+        """Run until the objective is wanted at ``self.x`` (True) or the run has ended (False)."""
+        while True:
+            self.g = self.g.astype(np.float64)
+            self._py._lbfgsb.setulb(self.m, self.x, self.low, self.up, self.nbd, self.f, self.g, self.factr, self.pgtol, self.wa, self.iwa,
+                                    self.task, self.lsave, self.isave, self.dsave, self.maxls, self.ln_task)
+            if self.task[0] == 3:
+                return True
+            if self.task[0] == 1:
+                self.nit += 1
+                if self.nit >= self.maxiter:
+                    self.task[0], self.task[1] = 5, 504
+                elif self.nfev > self.maxfun:
+                    self.task[0], self.task[1] = 5, 502
+            else:
+                self.done = True
+                return False
+
+    def answer(self, f: float, g: np.ndarray):
+        self.f, self.g = f, g
+        self.nfev += 1
+
+    def result(self):
+        from scipy.optimize import LbfgsInvHessProduct, OptimizeResult
+        if self.task[0] == 4:
+            warnflag = 0
+        elif self.nfev > self.maxfun or self.nit >= self.maxiter:
+            warnflag = 1
+        else:
+            warnflag = 2
+        m, n = self.m, self.n
+        s_, y_ = self.wa[0: m * n].reshape(m, n), self.wa[m * n: 2 * m * n].reshape(m, n)
+        n_corrs = min(self.isave[30], m)
+        message = self._py.status_messages[self.task[0]] + ': ' + self._py.task_messages[self.task[1]]
+        return OptimizeResult(fun=self.f, jac=self.g, nfev=self.nfev, njev=self.nfev, nit=self.nit, status=warnflag, message=message, x=self.x,
+                              success=(warnflag == 0), hess_inv=LbfgsInvHessProduct(s_[:n_corrs], y_[:n_corrs]))
+
+
+def _fit_reverse_communication(gps, problems, options, batch_lml_grad, max_units: int) -> list:
+    """Every unit's L-BFGS-B run advanced by ONE thread; each round of requests answered by batched evaluations."""
+    from romcomma_amd._lib import NotPositiveDefiniteError
+    n = len(gps)
+    results: list = [None] * n
+    runs: Dict[int, _SetulbRun] = {}
+    for u in range(n):
+        if not np.any(problems[u].mask):
+            results[u] = ('finish', None)
+            continue
+        try:
+            runs[u] = _SetulbRun(problems[u].x0, **options)
+        except Exception as failure:
+            results[u] = failure
+    live = sorted(runs)
+    while live:
+        asking, points = [], {}
+        for u in live:
+            try:
+                if runs[u].advance():
+                    points[u] = problems[u].theta(np.copy(runs[u].x))
+                    gps[u].set_hyper(*points[u][1])          # a point the library refuses fails ITS unit
+                    asking.append(u)
+                else:
+                    results[u] = ('finish', runs[u].result())
+            except Exception as failure:
+                results[u] = failure
+        for first in range(0, len(asking), max_units):
+            part = asking[first:first + max_units]
+            try:
+                lml, grad, status = batch_lml_grad([gps[u] for u in part])
+            except Exception as failure:                     # a failed call fails every unit in it
+                for u in part:
+                    results[u] = failure
+                continue
+            for k, u in enumerate(part):
+                if int(status[k]) > 0:
+                    results[u] = NotPositiveDefiniteError(int(status[k]), f'rcgp_lml_grad_batch: matrix is not positive definite: leading minor {int(status[k])}')
+                    continue
+                f, g = problems[u].loss_and_gradient(points[u][0], float(lml[k]), np.array(grad[k]))
+                runs[u].answer(f, g)
+        live = [u for u in asking if results[u] is None]
+    out = []
+    for u in range(n):
+        if isinstance(results[u], tuple):
+            try:
+                out.append(problems[u].finish(gps[u], results[u][1]))
+            except Exception as failure:
+                out.append(failure)
+        else:
+            out.append(results[u])
+    return out
+
+
+def _reverse_communication_ok() -> bool:
+    """Whether the installed SciPy's ``setulb`` can be driven as above: decided once, by running a small problem through
+    ``scipy.optimize.minimize`` and through ``_SetulbRun`` and asking for the same iterates, counts, message and printed result."""
+    if _RC_STATE['checked']:
+        return _RC_STATE['ok']
+    _RC_STATE['checked'] = True
+    try:
+        rng = np.random.default_rng(0)
+        A = rng.standard_normal((6, 6))
+        A = A @ A.T + np.eye(6)
+        b = rng.standard_normal(6)
+
+        def fun(x):                                           # a smooth non-quadratic bowl: several line-search steps per iteration
+            r = A @ x - b
+            return float(0.5 * r @ r + np.sum(np.cosh(0.3 * x))), A.T @ r + 0.3 * np.sinh(0.3 * x)
+        options = {'maxiter': 5000, 'gtol': 1e-16}
+        want = scipy.optimize.minimize(fun, np.full(6, 2.0), jac=True, method='L-BFGS-B', options=options)
+        run = _SetulbRun(np.full(6, 2.0), **options)
+        while run.advance():
+            run.answer(*fun(np.copy(run.x)))
+        got = run.result()
+        _RC_STATE['ok'] = bool(np.array_equal(got.x, want.x) and got.nfev == want.nfev and got.nit == want.nit and got.fun == want.fun and
+                               got.message == want.message and got.status == want.status and str(got) == str(want))
+    except Exception:
+        _RC_STATE['ok'] = False
+    return _RC_STATE['ok']
+
+
 def fit_lbfgsb_batch(gps: Sequence[Any], starts: Sequence[Dict[str, Any]], batch_lml_grad=None, max_units: Optional[int] = None,
-                     **common: Any) -> list:
+                     driver: Optional[str] = None, **common: Any) -> list:
     """``fit_lbfgsb`` for several units (``romcomma_amd._lib.RcGP`` of one device, equal M and padded size) at once.
 
     Args:
         starts: per unit the keyword arguments of ``fit_lbfgsb`` that differ between units (lengthscales, variance, noise, ...).
         common: keyword arguments shared by all units (is_isotropic, train_*, method, SciPy options).
         batch_lml_grad: the batched evaluation, ``romcomma_amd._lib.lml_grad_batch`` by default.
+        driver: 'setulb' (one thread driving SciPy's L-BFGS-B core by reverse communication), 'threads' (one ``minimize`` per unit in a
+            thread of its own), or None = the environment variable RCGP_LOCKSTEP, else 'setulb' where it applies -- method L-BFGS-B, no
+            callback, only the options ``_RC_OPTIONS``, and the self-check against ``minimize`` passed -- and 'threads' otherwise.
+            Both give every unit the fit it has alone.
     Returns: per unit the dict ``fit_lbfgsb`` returns -- identical to what a fit of that unit alone returns -- or, for a unit whose
         fit raised (e.g. a matrix that is not positive definite), the exception; the other units are not affected by it.
     """
@@ -195,6 +383,20 @@ def fit_lbfgsb_batch(gps: Sequence[Any], starts: Sequence[Dict[str, Any]], batch
             return [fit_lbfgsb(gps[0], **(dict(common) | dict(starts[0])))]
         except Exception as failure:
             return [failure]
+    if driver is None:
+        import os
+        driver = os.environ.get('RCGP_LOCKSTEP', 'setulb')
+    if driver == 'setulb':
+        merged = [dict(common) | dict(start) for start in starts]
+        keys = ('lengthscales', 'variance', 'noise', 'is_isotropic', 'train_lengthscales', 'train_variance', 'train_noise')
+        plain = all(m.get('method', 'L-BFGS-B') == 'L-BFGS-B' and m.get('callback') is None and
+                    set(m) - set(keys) - {'method', 'callback'} <= _RC_OPTIONS for m in merged)
+        options = [{k: v for k, v in m.items() if k in _RC_OPTIONS} for m in merged]
+        if plain and all(o == options[0] for o in options) and _reverse_communication_ok():
+            problems = [_FitProblem(gp.M, m['lengthscales'], m['variance'], m['noise'], m.get('is_isotropic', False),
+                                    m.get('train_lengthscales', True), m.get('train_variance', True), m.get('train_noise', True))
+                        for gp, m in zip(gps, merged)]
+            return _fit_reverse_communication(list(gps), problems, {'maxiter': 5000, 'gtol': 1e-16} | options[0], batch_lml_grad, max_units)
     lockstep = _Lockstep(gps, batch_lml_grad, max_units)
     results: list = [None] * len(gps)
 

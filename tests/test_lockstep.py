@@ -1,6 +1,8 @@
-"""Host logic of the lockstep fit driver (gpr/optimize.py::fit_lbfgsb_batch) on the CPU: the units' L-BFGS-B threads meet in one batched
+"""Host logic of the lockstep fit drivers (gpr/optimize.py::fit_lbfgsb_batch) on the CPU: the units' L-BFGS-B runs meet in one batched
 evaluation per round (the device calls are answered by the oracle here -- test infrastructure, never the product). What the reference
-does in its place: one gf.optimizers.Scipy().minimize per output, one after the other (gpr/models.py:359-361)."""
+does in its place: one gf.optimizers.Scipy().minimize per output, one after the other (gpr/models.py:359-361). Two drivers, the same
+fits: 'threads' (one scipy.optimize.minimize per unit in a thread of its own) and 'setulb' (one thread driving SciPy's compiled L-BFGS-B
+routine by reverse communication)."""
 import numpy as np
 import pytest
 
@@ -36,28 +38,63 @@ def batched(calls):
 
 
 START = dict(lengthscales=5.0 * np.ones(3), variance=2.0, noise=0.02)
+DRIVERS = pytest.mark.parametrize('driver', ['threads', 'setulb'])
 
 
-def test_lockstep_fits_equal_the_fits_alone_with_more_units_than_a_call_takes():
+def test_the_setulb_driver_is_in_use_on_this_scipy():
+    from romcomma_amd.gpr import optimize
+    assert optimize._reverse_communication_ok()                # scipy.optimize.minimize and the bare routine agree bit for bit here
+
+
+def same_fit(a, b):
+    return (a['nfev'] == b['nfev'] and a['log_marginal'] == b['log_marginal'] and np.array_equal(a['lengthscales'], b['lengthscales']) and
+            a['variance'] == b['variance'] and a['noise'] == b['noise'] and str(a['result']) == str(b['result']))
+
+
+@DRIVERS
+def test_lockstep_fits_equal_the_fits_alone_with_more_units_than_a_call_takes(driver):
     units = [Unit(*o.synthetic_fold(110 + 3 * k, 3, k=k)) for k in range(5)]
     alone = [fit_lbfgsb(u, **START) for u in units]
     calls = []
-    together = fit_lbfgsb_batch(units, [START] * 5, batch_lml_grad=batched(calls), max_units=2)
+    together = fit_lbfgsb_batch(units, [START] * 5, batch_lml_grad=batched(calls), max_units=2, driver=driver)
     assert max(calls) == 2 and min(calls) == 1                 # five live units: calls of 2 + 2 + 1, fewer as units converge
     for a, b in zip(alone, together):
-        assert a['nfev'] == b['nfev'] and a['log_marginal'] == b['log_marginal'] and np.array_equal(a['lengthscales'], b['lengthscales'])
+        assert same_fit(a, b)                                  # iterates, counts, message, the printed OptimizeResult that goes into meta.json
     assert len({a['nfev'] for a in alone}) > 1                 # the units leave at different rounds
 
 
-def test_a_point_the_library_refuses_fails_its_unit_only():
+@DRIVERS
+def test_every_kind_of_fit_the_host_asks_for(driver):
+    """Isotropic, parameters held fixed, other optimiser options, nothing trainable: each unit of a batch its own variant."""
+    variants = [dict(START, lengthscales=5.0, is_isotropic=True), dict(START, train_noise=False), dict(START, train_lengthscales=False),
+                dict(START, train_lengthscales=False, train_variance=False, train_noise=False)]
+    for options in ({}, {'maxiter': 7}, {'ftol': 1e-4, 'maxcor': 5, 'maxls': 10}):
+        units = [Unit(*o.synthetic_fold(90, 3, k=k)) for k in range(4)]
+        alone = [fit_lbfgsb(u, **v, **options) for u, v in zip(units, variants)]
+        together = fit_lbfgsb_batch(units, variants, batch_lml_grad=batched([]), max_units=8, driver=driver, **options)
+        for a, b in zip(alone, together):
+            assert same_fit(a, b), options
+        assert together[3]['result'] is None and together[3]['nfev'] == 0
+
+
+def test_options_the_setulb_driver_does_not_know_go_to_the_threads():
+    seen = []
+    units = [Unit(*o.synthetic_fold(80, 3, k=k)) for k in range(2)]
+    together = fit_lbfgsb_batch(units, [START] * 2, batch_lml_grad=batched([]), max_units=8, callback=lambda *a: seen.append(1))
+    assert seen and all(isinstance(t, dict) for t in together)  # a callback: scipy.optimize.minimize itself ran (in threads)
+
+
+@DRIVERS
+def test_a_point_the_library_refuses_fails_its_unit_only(driver):
     units = [Unit(*o.synthetic_fold(100, 3, k=k), refuse_after=(5 if k == 1 else None)) for k in range(3)]
-    out = fit_lbfgsb_batch(units, [START] * 3, batch_lml_grad=batched([]), max_units=8)
+    out = fit_lbfgsb_batch(units, [START] * 3, batch_lml_grad=batched([]), max_units=8, driver=driver)
     assert isinstance(out[1], ValueError) and isinstance(out[0], dict) and isinstance(out[2], dict)
     alone = fit_lbfgsb(Unit(*o.synthetic_fold(100, 3, k=2)), **START)
     assert out[2]['nfev'] == alone['nfev'] and out[2]['log_marginal'] == alone['log_marginal']
 
 
-def test_a_failed_batched_call_fails_the_units_of_its_round_and_nobody_hangs():
+@DRIVERS
+def test_a_failed_batched_call_fails_the_units_of_its_round_and_nobody_hangs(driver):
     units = [Unit(*o.synthetic_fold(90, 3, k=k)) for k in range(3)]
     state = {'n': 0}
 
@@ -66,11 +103,12 @@ def test_a_failed_batched_call_fails_the_units_of_its_round_and_nobody_hangs():
         if state['n'] == 4:
             raise RuntimeError('device lost')
         return batched([])(gps)
-    out = fit_lbfgsb_batch(units, [START] * 3, batch_lml_grad=flaky, max_units=8)
+    out = fit_lbfgsb_batch(units, [START] * 3, batch_lml_grad=flaky, max_units=8, driver=driver)
     assert all(isinstance(r, RuntimeError) for r in out)
 
 
-def test_status_words_become_not_positive_definite_errors():
+@DRIVERS
+def test_status_words_become_not_positive_definite_errors(driver):
     from romcomma_amd._lib import NotPositiveDefiniteError
     units = [Unit(*o.synthetic_fold(80, 3, k=k)) for k in range(2)]
 
@@ -79,5 +117,5 @@ def test_status_words_become_not_positive_definite_errors():
         if len(gps) == 2:
             status[1] = 17
         return lml, grad, status
-    out = fit_lbfgsb_batch(units, [START] * 2, batch_lml_grad=second_unit_singular, max_units=8)
+    out = fit_lbfgsb_batch(units, [START] * 2, batch_lml_grad=second_unit_singular, max_units=8, driver=driver)
     assert isinstance(out[1], NotPositiveDefiniteError) and out[1].k == 17 and isinstance(out[0], dict)
