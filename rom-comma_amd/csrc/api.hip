@@ -139,6 +139,7 @@ struct RcKnobs {
   int64_t nb = RC_NB_OUTER;
   int depth = 2, ext = 4;
   int tail = RC_TAIL_BLOCKS, lean = RC_LEAN_BLOCKS, farg = RC_FAR_GROUP;
+  bool nb_given = false, tail_given = false;
   int64_t half_tiles = RC_TRTRI_HALF_TILES;
   std::string seen;                                    // the values as first read, to recognise a later change
 };
@@ -177,11 +178,11 @@ static void read_knobs_once() {                          // (under g_streams_mut
   }
   if (const char* e = getenv("RCGP_NB")) {
     const int64_t nb = atoll(e);
-    if (nb >= 128 && nb <= 4096 && nb % 128 == 0) g_knobs.nb = nb;
+    if (nb >= 128 && nb <= 4096 && nb % 128 == 0) { g_knobs.nb = nb; g_knobs.nb_given = true; }
   }
   if (const char* e = getenv("RCGP_TAIL")) {           // block columns of the fine-grained tail panel; 0 = no tail
     const int x = atoi(e);
-    if (x >= 0 && x <= 4096) g_knobs.tail = x;
+    if (x >= 0 && x <= 4096) { g_knobs.tail = x; g_knobs.tail_given = true; }
   }
   if (const char* e = getenv("RCGP_FARG")) {           // far updates of the panel chain in groups of this many steps
     const int x = atoi(e);
@@ -225,6 +226,8 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
     h->chain_depth = g_knobs.depth;
     h->chain_ext = g_knobs.ext;
     h->tail_blocks = g_knobs.tail;
+    if (g_knobs.nb_given) h->batch_nb_outer = g_knobs.nb;          // an explicit knob holds for batches too
+    if (g_knobs.tail_given) h->batch_tail_blocks = g_knobs.tail;
     h->lean_blocks = g_knobs.lean;
     h->far_group = g_knobs.farg;
     h->trtri_half_tiles = g_knobs.half_tiles;

@@ -78,6 +78,8 @@ struct rcgp_handle_s {
   bool lookahead = true;             // RCGP_LOOKAHEAD: 0 = strictly sequential potrf on the main stream
   bool fine_chain = true;            // RCGP_FINE: 0 = one stream per panel chain (D, T, G in order), one-panel look-ahead
   int64_t nb_outer = RC_NB_OUTER;    // RCGP_NB: outer panel width
+  int64_t batch_nb_outer = 512;      // ... and what a BATCHED factorisation uses (potrf.hip): the environment's values if given, else 512 / 16 --
+  int batch_tail_blocks = 16;        // several units fill the chip, so the K = NB updates pay earlier (measured: DESIGN.md section 5)
   int chain_depth = 2;               // RCGP_DEPTH >= 1: column panels updated by their own kernels ahead of the bulk trailing update
   int tail_blocks = RC_TAIL_BLOCKS;   // RCGP_TAIL: the last this-many block columns of the factorisation form one fine-grained panel (potrf.hip)
   int lean_blocks = RC_LEAN_BLOCKS;   // RCGP_LEAN: chain steps with at most this many blocks below them carry ONE completion signal (potrf.hip)

@@ -544,7 +544,14 @@ static int next_event(rcgp_handle_s* h, hipEvent_t* out) {
 // (and the near part once it reaches column u0) does. Dependency events ride on the dispatches (RC_LAUNCH, h->launch_stop): one queue
 // packet less between two dependent kernels than a hipEventRecord marker.
 static int potrf_fine(rcgp_handle_s* h) {
-  const int64_t Np = h->Np, NB = h->nb_outer, EXT = 128 * (int64_t)h->chain_ext;
+  // A batched call (h->nb units per launch) runs narrower outer panels and a shorter tail than one unit alone: with several units the K = NB
+  // updates fill the chip from smaller trailing matrices on, and the all-fine-grained tail -- which trades throughput for latency -- pays
+  // only for the last 16 block columns (N = 8192, 4 units: 16.6 -> 15.4 ms; N = 4096, 16 units: 9.2 -> 8.8; profiles/r04_batch_knob_sweeps.txt).
+  // The schedule does not enter a unit's arithmetic (every tile adds its k-slabs in ascending order whatever delivers them), so the
+  // results stay bit-identical to the single-unit call: tests/test_gpu_batch.py.
+  const bool batched = h->nb > 1;
+  const int tail_blocks = batched ? h->batch_tail_blocks : h->tail_blocks;
+  const int64_t Np = h->Np, NB = batched ? h->batch_nb_outer : h->nb_outer, EXT = 128 * (int64_t)h->chain_ext;
   hipStream_t C = h->stream2, B = h->stream5, B2 = h->stream6, U1 = h->stream, U2 = h->stream3;
   int rc;
   hipEvent_t e0;
@@ -563,8 +570,8 @@ static int potrf_fine(rcgp_handle_s* h) {
   // chain's whole-CU kernel finds no empty CU beside it), while the K = 128 / 256 column work of a 40-block column hides behind the
   // chain's 73 us steps. The tail's updates reach to the last column, so they wait for EVERY outstanding K = NB update first.
   int64_t tail0 = Np;
-  if (h->tail_blocks > 0) {
-    const int64_t t = Np - 128 * (int64_t)h->tail_blocks;
+  if (tail_blocks > 0) {
+    const int64_t t = Np - 128 * (int64_t)tail_blocks;
     tail0 = (t <= 0) ? 0 : ((t + NB - 1) / NB) * NB;
     if (tail0 >= Np) tail0 = Np;
   }
