@@ -9,6 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # 1. the bench command itself under rocprofv3 --kernel-trace --stats
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench.err
+find $OUT/bench -name '*kernel_trace.csv' -delete      # (tens of MB: gpurun brings back at most 64 MiB; the stats csv beside it is what is kept)
 echo "bench under rocprof done" >&2
 # 2. one LML+gradient evaluation + Sobol at C2
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eval -- python3 tools/one_eval.py > $OUT/eval.log 2>&1
