@@ -42,7 +42,8 @@ int rcgp_version(void);
 /* Number of visible HIP devices, or a negative error. Does not create a context on any of them. */
 int rcgp_device_count(void);
 
-/* Upload the training fold: X is (N, M) row-major, y is (N). 1 <= M <= 64. */
+/* Upload the training fold: X is (N, M) row-major, y is (N). 1 <= M <= 256 (up to 64 dimensions the fused kernels stage a tile's inputs
+ * once; beyond that chunk by chunk: slower per evaluation, same results). */
 int rcgp_create(rcgp_handle* out, int device, int64_t N, int M, const double* X, const double* y);
 int rcgp_destroy(rcgp_handle h);
 const char* rcgp_last_error(rcgp_handle h);
@@ -92,8 +93,8 @@ int rcgp_sobol_cross(rcgp_handle h, const double* ell_j, double var_j, const dou
  * a == b entries the reference applies (:281, :284, :322):
  *   phi_d = mu_phi_mu term of the DIAGONAL rank equations (:259-288), psi_d = |psi_factor_ab|^2 (:311-322),
  *   phi_m, psi_m = the same under the MIXED rank equation (used when is_T_partial is false).
- * The caller assembles W = (phi - psi) + transpose and T (:324-346). Requires rcgp_factor. Any M <= 64 (beyond M = 29 the canonical
- * slices take several passes: their column accumulators no longer fit in LDS together). */
+ * The caller assembles W = (phi - psi) + transpose and T (:324-346). Requires rcgp_factor. M <= 64 (returns -2 beyond; beyond M = 29 the
+ * canonical slices take several passes: their column accumulators no longer fit in LDS together). */
 int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var_a, const double* alpha_a, int n_slices, const int32_t* slices,
                            double* phi_d, double* psi_d, double* phi_m, double* psi_m);
 

@@ -10,10 +10,13 @@
 
 #define RC_TILE 128            // edge of a workgroup tile and of a diagonal Cholesky block
 #define RC_BK 16               // k-depth of one LDS stage of the MFMA GEMM
-#define RC_MAX_M 64            // largest input dimensionality supported by the fused kernels
+#define RC_MAX_M 64            // largest input dimensionality of the fused FAST kernels (one staging of the Z / X panels per tile), of a covariant
+                               // GP and of the Sobol standard errors
+#define RC_MAX_M_WIDE 256      // largest input dimensionality of a single-output handle: beyond RC_MAX_M the Gram, gradient and Sobol kernels stage
+                               // their panels chunk by chunk (k_gram in chunks of 64 dimensions, k_grad<.., WIDE> of 32, k_sobol_pairs of 64)
 #define RC_MAX_L 16            // most outputs of one covariant GP
-#define RC_SCAL_ELEMS 256      // h->scal: [0,2) LML sums, [8, 8+M+2) gradient sums, [RC_SCAL_INFO] the Cholesky status word
-#define RC_SCAL_INFO 128
+#define RC_SCAL_ELEMS 512      // h->scal: [0,2) LML sums, [RC_SCAL_INFO] the Cholesky status word, [8, 8+M+2) gradient sums
+#define RC_SCAL_INFO 4
 #ifndef RC_TRTRI_HALF_TILES
 #define RC_TRTRI_HALF_TILES 1024
 #endif

@@ -795,7 +795,10 @@ __device__ __forceinline__ double rc_wave_sum(double v) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Tiles go out in row order of the lower triangle, heaviest k-ranges first by construction of tri_decode's enumeration (an 8 x 8
 // super-block order per XCD was measured: HBM reads -7 %, time +13 % -- DESIGN.md Appendix A.3).
-template <int LZ, int WN>
+// WIDE (M > RC_MAX_M = 64, up to RC_MAX_M_WIDE): the epilogue stages the Z panels of the tile in chunks of LZ - 1 = 32 dimensions -- per 16-row
+// group once for the dot products and once for the per-dimension sums -- instead of once per tile; the per-wave sums take RC_MAX_M_WIDE + 2 LDS
+// slots (one workgroup per CU then: a path for the rare wide design, not a fast one). The fast instantiations compile as before.
+template <int LZ, int WN, bool WIDE = false>
 __global__ void RC_BOUNDS(WN) k_grad(RcBP<const double> Linvb, int64_t ld, int64_t Np, RcBN Nv, int M, RcBP<const double> Zb, RcBP<const double> sqb,
                                      RcBP<const double> alphab, RcBP<const double> FSb, RcBP<double> partialb) {
   const double* __restrict__ Linv = Linvb.p[blockIdx.z];
@@ -808,7 +811,9 @@ __global__ void RC_BOUNDS(WN) k_grad(RcBP<const double> Linvb, int64_t ld, int64
   constexpr int ZL = 2 * 128 * LZ;
   constexpr int NW = 2 * WN;                                  // waves per workgroup
   constexpr int ZA = ZL + 4 * 128;                            // + alpha and sq of the tile's 128 rows and 128 columns
-  __shared__ double lds[(GEMM_LDS > ZA ? GEMM_LDS : ZA) + NW * (RC_MAX_M + 2)];
+  constexpr int RS = (WIDE ? RC_MAX_M_WIDE : RC_MAX_M) + 2;   // per-wave slots of the gradient sums
+  constexpr int MCH = LZ - 1;                                 // WIDE: dimensions staged at a time
+  __shared__ double lds[(GEMM_LDS > ZA ? GEMM_LDS : ZA) + NW * RS];
   int ti, tj;
   tri_decode(blockIdx.x, ti, tj);
   const int64_t kstart = (int64_t)ti * 128;
@@ -821,11 +826,15 @@ __global__ void RC_BOUNDS(WN) k_grad(RcBP<const double> Linvb, int64_t ld, int64
   double* zj = lds + 128 * LZ;
   double* ars = lds + ZL;                                     // alpha_i[128], sq_i[128], alpha_j[128], sq_j[128]
   double* red = lds + (GEMM_LDS > ZA ? GEMM_LDS : ZA);
-  for (int e = threadIdx.x; e < 128 * M; e += 128 * WN) {
-    const int rr = e / M, m = e - rr * M;
-    zi[rr * LZ + m] = Z[((int64_t)ti * 128 + rr) * M + m];
-    zj[rr * LZ + m] = Z[((int64_t)tj * 128 + rr) * M + m];
-  }
+  // dimensions [c0, c0 + mc) of the tile's Z rows and columns into LDS (WIDE: called by every wave at the same points of uniform loops)
+  auto stage_z = [&](int c0, int mc) {
+    for (int e = threadIdx.x; e < 128 * mc; e += 128 * WN) {
+      const int rr = e / mc, m = e - rr * mc;
+      zi[rr * LZ + m] = Z[((int64_t)ti * 128 + rr) * M + c0 + m];
+      zj[rr * LZ + m] = Z[((int64_t)tj * 128 + rr) * M + c0 + m];
+    }
+  };
+  if constexpr (!WIDE) stage_z(0, M);
   if (threadIdx.x < 128) {                                    // (through LDS: no 64-bit address arithmetic per element in the epilogue)
     ars[threadIdx.x] = alpha[(int64_t)ti * 128 + threadIdx.x];
     ars[128 + threadIdx.x] = sq[(int64_t)ti * 128 + threadIdx.x];
@@ -842,7 +851,11 @@ __global__ void RC_BOUNDS(WN) k_grad(RcBP<const double> Linvb, int64_t ld, int64
   }
   const int row0 = ti * 128, col0 = tj * 128;                 // (N < 2^31)
   auto wave_sum = [](double v) { return rc_wave_sum(v); };
-  if (lane_ < M) red[wave_ * (RC_MAX_M + 2) + lane_] = 0.0;    // this wave's M gradient sums, accumulated group by group (M <= 64 lanes)
+  if constexpr (!WIDE) {
+    if (lane_ < M) red[wave_ * RS + lane_] = 0.0;              // this wave's M gradient sums, accumulated group by group (M <= 64 lanes)
+  } else {
+    for (int m = lane_; m < M; m += 64) red[wave_ * RS + m] = 0.0;
+  }
   // One 16-row group (8 elements per lane) at a time, START TO END: its dot products in 8 registers, its eight W.K values, and at once
   // their M gradient sums (reduced over the wave and added into the wave's LDS slots by lane 0) -- so the group's accumulators are dead
   // when the next group starts. Written as 32 independent element evaluations followed by one pass per m over all 32, the compiler
@@ -859,17 +872,31 @@ __global__ void RC_BOUNDS(WN) k_grad(RcBP<const double> Linvb, int64_t ld, int64
     // runs the four dot loops first, parks 32 dot products in scratch memory, and evaluates the 32 exps afterwards)
     int mcount = M;
     asm volatile("" : "+s"(mcount), "+v"(gvar));
+    auto dot_over = [&](int mc) {                              // dot products over the mc dimensions in LDS
 #pragma unroll 1
-    for (int m = 0; m < mcount; ++m) {
-      double zr[4], zc[NI_];
+      for (int m = 0; m < mc; ++m) {
+        double zr[4], zc[NI_];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zr[r] = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
+        for (int r = 0; r < 4; ++r) zr[r] = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
 #pragma unroll
-      for (int ni = 0; ni < NI_; ++ni) zc[ni] = zj[(wc_ + 16 * ni + fr_) * LZ + m];
+        for (int ni = 0; ni < NI_; ++ni) zc[ni] = zj[(wc_ + 16 * ni + fr_) * LZ + m];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int ni = 0; ni < NI_; ++ni) dot[r][ni] = fma(zr[r], zc[ni], dot[r][ni]);
+          for (int ni = 0; ni < NI_; ++ni) dot[r][ni] = fma(zr[r], zc[ni], dot[r][ni]);
+      }
+    };
+    if constexpr (!WIDE) {
+      dot_over(mcount);                                        // all M dimensions, staged once per tile
+    } else {
+#pragma unroll 1
+      for (int c0 = 0; c0 < mcount; c0 += MCH) {
+        const int mc = (mcount - c0 < MCH) ? mcount - c0 : MCH;
+        __syncthreads();                                       // (everybody has read the chunk staged before)
+        stage_z(c0, mc);
+        __syncthreads();
+        dot_over(mc);
+      }
     }
     double wk[4][NI_];
 #pragma unroll
@@ -890,34 +917,48 @@ __global__ void RC_BOUNDS(WN) k_grad(RcBP<const double> Linvb, int64_t ld, int64
         if (valid && j == i) gnoise += wij;
       }
     }
+    auto sums_over = [&](int c0, int mc) {                     // the per-dimension gradient sums of the mc dimensions in LDS (dimension c0 + m)
 #pragma unroll 1
-    for (int m = 0; m < mcount; ++m) {
-      double g = 0.0;
+      for (int m = 0; m < mc; ++m) {
+        double g = 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double zim = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
+        for (int r = 0; r < 4; ++r) {
+          const double zim = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
 #pragma unroll
-        for (int ni = 0; ni < NI_; ++ni) {
-          const double d = zim - zj[(wc_ + 16 * ni + fr_) * LZ + m];
-          g = fma(wk[r][ni], d * d, g);
+          for (int ni = 0; ni < NI_; ++ni) {
+            const double d = zim - zj[(wc_ + 16 * ni + fr_) * LZ + m];
+            g = fma(wk[r][ni], d * d, g);
+          }
         }
+        g = wave_sum(g);
+        if (lane_ == 0) red[wave_ * RS + c0 + m] += g;
       }
-      g = wave_sum(g);
-      if (lane_ == 0) red[wave_ * (RC_MAX_M + 2) + m] += g;
+    };
+    if constexpr (!WIDE) {
+      sums_over(0, mcount);
+    } else {
+#pragma unroll 1
+      for (int c0 = 0; c0 < mcount; c0 += MCH) {
+        const int mc = (mcount - c0 < MCH) ? mcount - c0 : MCH;
+        __syncthreads();
+        stage_z(c0, mc);
+        __syncthreads();
+        sums_over(c0, mc);
+      }
     }
   }
   gvar = wave_sum(gvar);
   gnoise = wave_sum(gnoise);
   if (lane_ == 0) {
-    red[wave_ * (RC_MAX_M + 2) + M] = gvar;
-    red[wave_ * (RC_MAX_M + 2) + M + 1] = gnoise;
+    red[wave_ * RS + M] = gvar;
+    red[wave_ * RS + M + 1] = gnoise;
   }
   __syncthreads();
   if (threadIdx.x < M + 2) {
     const int m = threadIdx.x;
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) s += red[w * (RC_MAX_M + 2) + m];      // fixed order: bit-reproducible
+    for (int w = 0; w < NW; ++w) s += red[w * RS + m];      // fixed order: bit-reproducible
     partial[tile_id * (M + 2) + m] = s;
   }
 }
@@ -939,8 +980,10 @@ int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
   const dim3 grid((unsigned)nb, 1, (unsigned)h->nb);
   if (h->M <= 32)
     hipLaunchKernelGGL((k_grad<33, RC_WN>), grid, dim3(128 * RC_WN), 0, h->launch, Lb, h->Np, h->Np, rc_bn(h), h->M, Zb, sb, ab, Fb, pb);
-  else
+  else if (h->M <= RC_MAX_M)
     hipLaunchKernelGGL((k_grad<65, RC_WN>), grid, dim3(128 * RC_WN), 0, h->launch, Lb, h->Np, h->Np, rc_bn(h), h->M, Zb, sb, ab, Fb, pb);
+  else
+    hipLaunchKernelGGL((k_grad<33, RC_WN, true>), grid, dim3(128 * RC_WN), 0, h->launch, Lb, h->Np, h->Np, rc_bn(h), h->M, Zb, sb, ab, Fb, pb);
   RC_HIP(hipGetLastError());
   *nrows = (int)nb;
   return 0;

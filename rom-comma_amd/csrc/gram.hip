@@ -66,7 +66,9 @@ __device__ __forceinline__ void tri_decode_g(int64_t id, int& ti, int& tj) {
 // nr_valid / nc_valid count the valid rows of ONE block. The test points of a cross-Gram all belong to output rb.
 // 512 threads per 128x128 tile, 32 outputs per thread (the C/D layout of 4 x 2 MFMA tiles per wave): <= 128 registers, so four
 // waves per SIMD are resident and the store phase of one wave overlaps the exp phase of the others.
-template <bool CROSS>
+// WIDE (M > RC_MAX_M = 64): the dimensions pass through LDS in chunks of 64, the dot products accumulating in the MFMA accumulators across
+// chunks; the fast instantiation stages the whole panels once, exactly as before.
+template <bool CROSS, bool WIDE = false>
 __global__ void __launch_bounds__(512, 4) k_gram(RcBP<double> outb, int64_t ld, RcBP<const double> Zrb, RcBP<const double> sqrb, int64_t nr_cross,
                                                  RcBP<const double> Zcb, RcBP<const double> sqcb, RcBN ncv, int M, RcBP<const double> FSb, int L,
                                                  int tb, int rb) {
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(512, 4) k_gram(RcBP<double> outb, int64_t ld, 
   const double* __restrict__ sqc = sqcb.p[unit];
   const double* __restrict__ FS = FSb.p[unit];
   const int64_t nc_valid = ncv.v[unit], nr_valid = CROSS ? nr_cross : nc_valid;
-  const int Mp = (M + 3) & ~3;     // dimensions padded to a multiple of four (one fp64 MFMA consumes four), the padding zero
+  const int Mp = WIDE ? RC_MAX_M : ((M + 3) & ~3);     // dimensions (of a chunk) padded to a multiple of four (one fp64 MFMA consumes four), the padding zero
   double* zi = sm;                 // [Mp][ZST]
   double* zj = sm + Mp * ZST;      // [Mp][ZST]
   double* si = zj + Mp * ZST;      // [128]
@@ -97,32 +99,36 @@ __global__ void __launch_bounds__(512, 4) k_gram(RcBP<double> outb, int64_t ld, 
   const double var = FS[bi * L + bj], noise = CROSS ? 0.0 : FS[L * L + bi * L + bj];
   const int64_t ioff = CROSS ? 0 : (int64_t)bi * tb * 128, joff = (int64_t)bj * tb * 128;   // first row / column of the block
   const int t = threadIdx.x;
-  for (int e0 = t; e0 < 128 * M; e0 += 4 * 512) {    // four loads per panel in flight before the first LDS store (not one round trip each)
-    double vi[4], vj[4];
+  if constexpr (!WIDE) {
+    for (int e0 = t; e0 < 128 * M; e0 += 4 * 512) {    // four loads per panel in flight before the first LDS store (not one round trip each)
+      double vi[4], vj[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = e0 + 512 * q;
-      vi[q] = (e < 128 * M) ? Zr[(int64_t)ti * 128 * M + e] : 0.0;
-      vj[q] = (e < 128 * M) ? Zc[(int64_t)tj * 128 * M + e] : 0.0;
-    }
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + 512 * q;
+        vi[q] = (e < 128 * M) ? Zr[(int64_t)ti * 128 * M + e] : 0.0;
+        vj[q] = (e < 128 * M) ? Zc[(int64_t)tj * 128 * M + e] : 0.0;
+      }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = e0 + 512 * q;
-      if (e < 128 * M) {
-        const int rr = e / M, m = e - rr * M;
-        zi[m * ZST + rr] = vi[q];
-        zj[m * ZST + rr] = vj[q];
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + 512 * q;
+        if (e < 128 * M) {
+          const int rr = e / M, m = e - rr * M;
+          zi[m * ZST + rr] = vi[q];
+          zj[m * ZST + rr] = vj[q];
+        }
       }
     }
   }
   if (t < 128) si[t] = sqr[(int64_t)ti * 128 + t];
   else if (t < 256) sj[t - 128] = sqc[(int64_t)tj * 128 + t - 128];
-  for (int e = t; e < (Mp - M) * 128; e += 512) {
-    const int m = M + e / 128, rr = e & 127;
-    zi[m * ZST + rr] = 0.0;
-    zj[m * ZST + rr] = 0.0;
+  if constexpr (!WIDE) {
+    for (int e = t; e < (Mp - M) * 128; e += 512) {
+      const int m = M + e / 128, rr = e & 127;
+      zi[m * ZST + rr] = 0.0;
+      zj[m * ZST + rr] = 0.0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // z_i . z_j on the matrix cores (the -2 Z Z^T term of the squared-distance expansion IS a 128 x 128 x M product): 8 waves as 2 x 4, a wave
   // owns 64 x 32 = 4 x 2 MFMA tiles; A lane l = zi[k = l >> 4][row l & 15], B lane l = zj[k = l >> 4][col l & 15] -- both contiguous reads of
   // the m-major panels; the panels are zero-padded to a multiple of four dimensions. The M fp64 FMAs per element this replaces were 10 of the
@@ -135,16 +141,45 @@ __global__ void __launch_bounds__(512, 4) k_gram(RcBP<double> outb, int64_t ld, 
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int c = 0; c < 2; ++c) acc[a][c] = (v4d){0.0, 0.0, 0.0, 0.0};
-  for (int m0 = 0; m0 < Mp; m0 += 4) {
-    double af[4], bf[2];
+  if constexpr (!WIDE) {
+    for (int m0 = 0; m0 < Mp; m0 += 4) {
+      double af[4], bf[2];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) af[x] = zi[(m0 + fq) * ZST + wr + 16 * x + fr];
+      for (int x = 0; x < 4; ++x) af[x] = zi[(m0 + fq) * ZST + wr + 16 * x + fr];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) bf[x] = zj[(m0 + fq) * ZST + wc + 16 * x + fr];
+      for (int x = 0; x < 2; ++x) bf[x] = zj[(m0 + fq) * ZST + wc + 16 * x + fr];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+  } else {
+    for (int mc = 0; mc < M; mc += RC_MAX_M) {                   // dimension chunks [mc, mc + Mc)
+      const int Mc = (M - mc < RC_MAX_M) ? M - mc : RC_MAX_M, Mcp = (Mc + 3) & ~3;
+      __syncthreads();                                           // (everybody has read the previous chunk; si / sj are in place)
+      for (int e = t; e < 128 * Mc; e += 512) {
+        const int rr = e / Mc, m = e - rr * Mc;
+        zi[m * ZST + rr] = Zr[((int64_t)ti * 128 + rr) * M + mc + m];
+        zj[m * ZST + rr] = Zc[((int64_t)tj * 128 + rr) * M + mc + m];
+      }
+      for (int e = t; e < (Mcp - Mc) * 128; e += 512) {
+        const int m = Mc + e / 128, rr = e & 127;
+        zi[m * ZST + rr] = 0.0;
+        zj[m * ZST + rr] = 0.0;
+      }
+      __syncthreads();
+      for (int m0 = 0; m0 < Mcp; m0 += 4) {
+        double af[4], bf[2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) af[x] = zi[(m0 + fq) * ZST + wr + 16 * x + fr];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) bf[x] = zj[(m0 + fq) * ZST + wc + 16 * x + fr];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
   }
   // C/D layout: lane l, register r of tile (mi, ni) is element (row wr + 16 mi + 4 r + (l >> 4), column wc + 16 ni + (l & 15)): a store
   // instruction writes four rows x 128 contiguous bytes.
@@ -189,12 +224,16 @@ __global__ void __launch_bounds__(512, 4) k_gram(RcBP<double> outb, int64_t ld, 
     }
 }
 
-static size_t gram_lds_bytes(int M) { return (size_t)(2 * ((M + 3) & ~3) * ZST + 256) * sizeof(double); }
+static size_t gram_lds_bytes(int M) {
+  const int Mc = (M < RC_MAX_M) ? M : RC_MAX_M;                  // the kernel stages at most RC_MAX_M dimensions at a time
+  return (size_t)(2 * ((Mc + 3) & ~3) * ZST + 256) * sizeof(double);
+}
 
 int rc_launch_gram(rcgp_handle_s* h) {
   const int64_t T = h->Np / 128;
   const size_t lds = gram_lds_bytes(h->M);
-  RC_HIP(hipFuncSetAttribute((const void*)k_gram<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool wide = h->M > RC_MAX_M;
+  RC_HIP(hipFuncSetAttribute(wide ? (const void*)k_gram<false, true> : (const void*)k_gram<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const double N = (double)h->N * (double)h->L;
   RC_BP(double, Ab, h->A)
   RC_BP(const double, Zb, h->Z)
@@ -202,22 +241,31 @@ int rc_launch_gram(rcgp_handle_s* h) {
   RC_BP(const double, Fb, h->FS_d)
   // (profiling events ride on the dispatch itself: a pair of hipEventRecord markers brackets 15-60 us more than this 60-220 us kernel runs)
   RcProfScope ps(h, RC_K_GRAM, (double)h->nb * 8.0 * (N * (N + 1.0) / 2.0 + N * (double)h->M), true);   // algorithmic bytes
-  RC_LAUNCH((k_gram<false>), dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)h->nb), dim3(512), lds, Ab, h->Np, Zb, sb, (int64_t)0, Zb, sb, rc_bn(h), h->M, Fb,
-            h->L, (int)(h->Nb / 128), 0);
+  const dim3 grid((unsigned)(T * (T + 1) / 2), 1, (unsigned)h->nb);
+  if (wide) {
+    RC_LAUNCH((k_gram<false, true>), grid, dim3(512), lds, Ab, h->Np, Zb, sb, (int64_t)0, Zb, sb, rc_bn(h), h->M, Fb, h->L, (int)(h->Nb / 128), 0);
+  } else {
+    RC_LAUNCH((k_gram<false, false>), grid, dim3(512), lds, Ab, h->Np, Zb, sb, (int64_t)0, Zb, sb, rc_bn(h), h->M, Fb, h->L, (int)(h->Nb / 128), 0);
+  }
   RC_HIP(hipGetLastError());
   return 0;
 }
 
 int rc_launch_cross_gram(rcgp_handle_s* h, int64_t n, int64_t np, int out) {
   const size_t lds = gram_lds_bytes(h->M);
-  RC_HIP(hipFuncSetAttribute((const void*)k_gram<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool wide = h->M > RC_MAX_M;
+  RC_HIP(hipFuncSetAttribute(wide ? (const void*)k_gram<true, true> : (const void*)k_gram<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   RcProfScope ps(h, RC_K_MISC, 0.0);
   RcBP<double> Kb = {{h->KsT}};
   RcBP<const double> Zsb = {{h->Zs}}, ssb = {{h->sqs}}, Zb = {{h->Z}}, sb = {{h->sq}}, Fb = {{h->FS_d}};
   RcBN nv;
   for (int u = 0; u < RC_MAX_BATCH; ++u) nv.v[u] = h->N;
-  hipLaunchKernelGGL(k_gram<true>, dim3((unsigned)(h->Np / 128), (unsigned)(np / 128)), dim3(512), lds, h->launch, Kb, h->Np, Zsb, ssb, n, Zb, sb, nv,
-                     h->M, Fb, h->L, (int)(h->Nb / 128), out);
+  if (wide)
+    hipLaunchKernelGGL((k_gram<true, true>), dim3((unsigned)(h->Np / 128), (unsigned)(np / 128)), dim3(512), lds, h->launch, Kb, h->Np, Zsb, ssb, n, Zb, sb,
+                       nv, h->M, Fb, h->L, (int)(h->Nb / 128), out);
+  else
+    hipLaunchKernelGGL((k_gram<true, false>), dim3((unsigned)(h->Np / 128), (unsigned)(np / 128)), dim3(512), lds, h->launch, Kb, h->Np, Zsb, ssb, n, Zb, sb,
+                       nv, h->M, Fb, h->L, (int)(h->Nb / 128), out);
   RC_HIP(hipGetLastError());
   return 0;
 }

@@ -54,14 +54,19 @@ __global__ void k_sobol_center(double* __restrict__ g, int64_t N, const double* 
 // Pair-tile kernel. consts = [c0 | c2 | pl | pj] (4 x M). Output partial[blk][3*M]: first[m], closed[m], total[m] where
 // total[m] is the slice [m+1, M) (total[M-1] = empty slice, left 0 here and filled by the caller).
 // mode 0: canonical (all three kinds). mode 1: one arbitrary slice [ma, mb), result in column 0.
-template <bool SYM>
+template <bool SYM, bool WIDE = false>
 __global__ void __launch_bounds__(256) k_sobol_pairs(const double* __restrict__ X, const double* __restrict__ gl,
                                                      const double* __restrict__ gj, const double* __restrict__ consts, int M, int mode,
                                                      int ma, int mb, double* __restrict__ partial) {
   extern __shared__ double sm[];
-  double* xi = sm;                     // [M][XST]
-  double* xj = sm + M * XST;           // [M][XST]
-  double* wsum = xj + M * XST;         // [4][3*M]
+  // The X panels of the tile pass through LDS in chunks of MC = min(M, RC_MAX_M) dimensions: ONE chunk up to M = 64 (staged once, the fast
+  // path); beyond that the ascending pass stages the chunks in rising order and the descending pass in falling order -- the running
+  // exponent sums live in registers, so a chunk is needed only while its dimensions are being added.
+  const int MC = WIDE ? RC_MAX_M : M;
+  constexpr bool chunked = WIDE;
+  double* xi = sm;                     // [MC][XST]
+  double* xj = sm + MC * XST;          // [MC][XST]
+  double* wsum = xj + MC * XST;        // [4][3*M]
   int ti, tj;
   if (SYM) {
     int t = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -75,10 +80,22 @@ __global__ void __launch_bounds__(256) k_sobol_pairs(const double* __restrict__ 
   }
   const int64_t blk = SYM ? (int64_t)blockIdx.x : (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int e = t; e < 128 * M; e += 256) {
-    const int rr = e / M, m = e - rr * M;
-    xi[m * XST + rr] = X[((int64_t)ti * 128 + rr) * M + m];
-    xj[m * XST + rr] = X[((int64_t)tj * 128 + rr) * M + m];
+  int cb = 0;                                                 // first dimension of the chunk in LDS (stays 0 on the fast path)
+  auto stage = [&](int c0) {                                  // dimensions [c0, c0 + MC) (every thread calls it at the same points of uniform loops)
+    cb = c0;
+    const int mc = (M - c0 < MC) ? M - c0 : MC;
+    for (int e = t; e < 128 * mc; e += 256) {
+      const int rr = e / mc, m = e - rr * mc;
+      xi[m * XST + rr] = X[((int64_t)ti * 128 + rr) * M + c0 + m];
+      xj[m * XST + rr] = X[((int64_t)tj * 128 + rr) * M + c0 + m];
+    }
+  };
+  if constexpr (!WIDE) {
+    for (int e = t; e < 128 * M; e += 256) {
+      const int rr = e / M, m = e - rr * M;
+      xi[m * XST + rr] = X[((int64_t)ti * 128 + rr) * M + m];
+      xj[m * XST + rr] = X[((int64_t)tj * 128 + rr) * M + m];
+    }
   }
   for (int e = t; e < 4 * 3 * M; e += 256) wsum[e] = 0.0;
   const int tx = t & 15, ty = t >> 4;
@@ -108,17 +125,24 @@ __global__ void __launch_bounds__(256) k_sobol_pairs(const double* __restrict__ 
     for (int c = 0; c < 8; ++c) e[a][c] = 0.0;
   const int m_lo = (mode == 0) ? 0 : ma, m_hi = (mode == 0) ? M : mb;
   for (int m = m_lo; m < m_hi; ++m) {
+    if constexpr (chunked) {
+      if (m == m_lo || m % MC == 0) {                         // the chunk that holds dimension m
+        __syncthreads();
+        stage((m / MC) * MC);
+        __syncthreads();
+      }
+    }
     const double k0 = c0[m], k2 = c2[m], kl = pl[m], kj = pj[m];
     double ai[8], ui[8], bj[8], xc[8];
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      const double x = xi[m * XST + ty + 16 * a];
+      const double x = xi[(m - cb) * XST + ty + 16 * a];
       ai[a] = fma(kl * x, x, k0);
       ui[a] = k2 * x;
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const double2 x = *reinterpret_cast<const double2*>(xj + m * XST + 2 * tx + 32 * b);
+      const double2 x = *reinterpret_cast<const double2*>(xj + (m - cb) * XST + 2 * tx + 32 * b);
       xc[2 * b] = x.x;
       xc[2 * b + 1] = x.y;
       bj[2 * b] = kj * x.x * x.x;
@@ -167,17 +191,24 @@ __global__ void __launch_bounds__(256) k_sobol_pairs(const double* __restrict__ 
 #pragma unroll
       for (int c = 0; c < 8; ++c) e[a][c] = 0.0;
     for (int m = M - 1; m >= 1; --m) {
+      if constexpr (chunked) {
+        if (m == M - 1 || m % MC == MC - 1) {
+          __syncthreads();
+          stage((m / MC) * MC);
+          __syncthreads();
+        }
+      }
       const double k0 = c0[m], k2 = c2[m], kl = pl[m], kj = pj[m];
       double ai[8], ui[8], bj[8], xc[8];
 #pragma unroll
       for (int a = 0; a < 8; ++a) {
-        const double x = xi[m * XST + ty + 16 * a];
+        const double x = xi[(m - cb) * XST + ty + 16 * a];
         ai[a] = fma(kl * x, x, k0);
         ui[a] = k2 * x;
       }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const double2 x = *reinterpret_cast<const double2*>(xj + m * XST + 2 * tx + 32 * b);
+        const double2 x = *reinterpret_cast<const double2*>(xj + (m - cb) * XST + 2 * tx + 32 * b);
         xc[2 * b] = x.x;
         xc[2 * b + 1] = x.y;
         bj[2 * b] = kj * x.x * x.x;
@@ -262,19 +293,28 @@ static int sobol_run_slices(rcgp_handle_s* h, int64_t Np, const double* g_l, con
   const int64_t nblk = sym ? T * (T + 1) / 2 : T * T;
   rc = rc_ensure_partial(h, (size_t)nblk * 3 * M);
   if (rc) return rc;
-  const size_t lds = (size_t)(2 * M * XST + 4 * 3 * M) * sizeof(double);
-  RC_HIP(hipFuncSetAttribute((const void*)k_sobol_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  RC_HIP(hipFuncSetAttribute((const void*)k_sobol_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = (size_t)(2 * (M < RC_MAX_M ? M : RC_MAX_M) * XST + 4 * 3 * M) * sizeof(double);      // (panels in chunks of <= 64 dimensions)
+  const bool wide = M > RC_MAX_M;
+  RC_HIP(hipFuncSetAttribute(wide ? (const void*)k_sobol_pairs<true, true> : (const void*)k_sobol_pairs<true, false>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RC_HIP(hipFuncSetAttribute(wide ? (const void*)k_sobol_pairs<false, true> : (const void*)k_sobol_pairs<false, false>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const double pairs = sym ? (double)h->N * ((double)h->N + 1.0) / 2.0 : (double)h->N * (double)h->N;
 
   auto run = [&](int mode, int ma, int mb, std::vector<double>& out) -> int {
     {
       RcProfScope ps(h, RC_K_SOBOL, pairs * (mode == 0 ? (double)(3 * M - 1) : 1.0));     // exp evaluations
-      if (sym)
-        hipLaunchKernelGGL(k_sobol_pairs<true>, dim3((unsigned)nblk), dim3(256), lds, h->stream, h->X, g_l, g_j, consts_d, M, mode, ma, mb,
+      if (sym && !wide)
+        hipLaunchKernelGGL((k_sobol_pairs<true, false>), dim3((unsigned)nblk), dim3(256), lds, h->stream, h->X, g_l, g_j, consts_d, M, mode, ma, mb,
                            h->partial);
+      else if (sym)
+        hipLaunchKernelGGL((k_sobol_pairs<true, true>), dim3((unsigned)nblk), dim3(256), lds, h->stream, h->X, g_l, g_j, consts_d, M, mode, ma, mb,
+                           h->partial);
+      else if (!wide)
+        hipLaunchKernelGGL((k_sobol_pairs<false, false>), dim3((unsigned)T, (unsigned)T), dim3(256), lds, h->stream, h->X, g_l, g_j, consts_d, M,
+                           mode, ma, mb, h->partial);
       else
-        hipLaunchKernelGGL(k_sobol_pairs<false>, dim3((unsigned)T, (unsigned)T), dim3(256), lds, h->stream, h->X, g_l, g_j, consts_d, M,
+        hipLaunchKernelGGL((k_sobol_pairs<false, true>), dim3((unsigned)T, (unsigned)T), dim3(256), lds, h->stream, h->X, g_l, g_j, consts_d, M,
                            mode, ma, mb, h->partial);
       RC_HIP(hipGetLastError());
     }

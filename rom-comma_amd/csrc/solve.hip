@@ -154,7 +154,8 @@ int rc_alpha(rcgp_handle_s* h) {
 // Deterministic single-block reductions: out[0] = sum w^2, out[1] = sum logdiag.
 // With `gather` (a batched evaluation): the unit's whole result block -- these two sums, its gradient sums (already in scal[8 ...]) and its
 // Cholesky status word -- is copied into row blockIdx.z of the leader's result table, so that ONE copy brings every unit's numbers down.
-__global__ void __launch_bounds__(1024) k_lml_reduce(RcBP<const double> wb, RcBP<const double> logdiagb, int64_t n, RcBP<double> outb, double* gather) {
+__global__ void __launch_bounds__(1024) k_lml_reduce(RcBP<const double> wb, RcBP<const double> logdiagb, int64_t n, RcBP<double> outb, double* gather,
+                                                     int ncopy) {
   __shared__ double sa[1024], sb[1024];
   const double* __restrict__ w = wb.p[blockIdx.z];
   const double* __restrict__ logdiag = logdiagb.p[blockIdx.z];
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(1024) k_lml_reduce(RcBP<const double> wb, RcBP
   if (gather) {
     double* g = gather + (size_t)blockIdx.z * RC_SCAL_ELEMS;
     if (threadIdx.x == 0) { g[0] = sa[0]; g[1] = sb[0]; }
-    else if (threadIdx.x >= 2 && threadIdx.x <= RC_SCAL_INFO) g[threadIdx.x] = out[threadIdx.x];
+    else if (threadIdx.x >= 2 && (int)threadIdx.x < ncopy) g[threadIdx.x] = out[threadIdx.x];       // status word [4], gradient sums [8, 8 + M + 2)
   }
 }
 
@@ -189,11 +190,12 @@ int rc_lml_value(rcgp_handle_s* h, double* lml) {
     RcProfScope ps(h, RC_K_MISC, 0.0);
     RcBP<const double> wb = {{h->w}}, lb = {{h->logdiag}};
     RcBP<double> ob = {{h->scal}};
-    hipLaunchKernelGGL(k_lml_reduce, dim3(1), dim3(1024), 0, h->stream, wb, lb, h->Np, ob, (double*)nullptr);
+    hipLaunchKernelGGL(k_lml_reduce, dim3(1), dim3(1024), 0, h->stream, wb, lb, h->Np, ob, (double*)nullptr, 0);
     RC_HIP(hipGetLastError());
   }
   double* host = h->pin + h->pin_result;
-  RC_HIP(hipMemcpyAsync(host, h->scal, (RC_SCAL_INFO + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  const size_t n_result = 8 + (h->L == 1 ? (size_t)h->M + 2 : 0);       // LML sums, status word, (single output) the gradient sums
+  RC_HIP(hipMemcpyAsync(host, h->scal, n_result * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   RC_HIP(hipStreamSynchronize(h->stream));
   if (h->profiling) rc_prof_collect(h);      // the stream is idle here: harvesting the events costs no extra sync
   int info = 0;
@@ -240,7 +242,7 @@ int rc_batch_lml_reduce(rcgp_handle_s* h) {
   RC_BP(const double, lb, h->logdiag)
   RC_BP(double, ob, h->scal)
   RcProfScope ps(h, RC_K_MISC, 0.0);
-  hipLaunchKernelGGL(k_lml_reduce, dim3(1, 1, (unsigned)h->nb), dim3(1024), 0, h->stream, wb, lb, h->Np, ob, h->bres_d);
+  hipLaunchKernelGGL(k_lml_reduce, dim3(1, 1, (unsigned)h->nb), dim3(1024), 0, h->stream, wb, lb, h->Np, ob, h->bres_d, 8 + h->M + 2);
   RC_HIP(hipGetLastError());
   return 0;
 }

@@ -253,3 +253,29 @@ def test_run_gpr_over_folds_at_once_writes_what_fold_after_fold_writes(gpu, tmp_
              ('kernel/lengthscales.csv', 'kernel/variance.csv', 'likelihood/variance.csv', 'likelihood/log_marginal.csv', 'test.csv', 'test_summary.csv')]
     for rel in [f'fold.{k}/{f}' for k in range(4) for f in files] + files:
         assert (repos[1].folder / rel).read_bytes() == (repos[4].folder / rel).read_bytes(), rel
+
+
+def test_wide_designs_in_a_batch(gpu):
+    """M = 80 > 64 (the chunked Gram / gradient kernels) through the batched entry: bit-identical to the single-handle call and
+    equal to the oracle."""
+    M = 80
+    gps, data = _units(gpu, (300, 330), M, seed_offset=70)
+    rng = np.random.default_rng(1)
+    thetas = [(rng.uniform(3.0, 9.0, M), 1.1 + 0.2 * u, 0.02) for u in range(2)]
+    for gp, t in zip(gps, thetas):
+        gp.set_hyper(*t)
+    single = [gp.lml_grad() for gp in gps]
+    for gp, t in zip(gps, thetas):
+        gp.set_hyper(t[0] * 1.01, t[1], t[2])
+    gpu.lml_grad_batch(gps)
+    for gp, t in zip(gps, thetas):
+        gp.set_hyper(*t)
+    lml, grad, status = gpu.lml_grad_batch(gps)
+    assert np.all(status == 0)
+    for u, ((X, y), t) in enumerate(zip(data, thetas)):
+        assert lml[u] == single[u][0] and np.array_equal(grad[u], single[u][1])
+        ref_lml, ref_grad = o.lml_and_grad(X, y, *t)
+        assert lml[u] == pytest.approx(ref_lml, rel=1e-10)
+        np.testing.assert_allclose(grad[u], ref_grad, rtol=1e-7, atol=1e-9 * np.max(np.abs(ref_grad)))
+    for gp in gps:
+        gp.close()

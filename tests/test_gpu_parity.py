@@ -70,7 +70,8 @@ def test_literal_multi_output_fixture(gpu):
 # oracle on seeded inputs, incl. ragged sizes around the 128 tile edge and the extremes of M
 # --------------------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize('N,M', [(1, 1), (2, 3), (127, 2), (128, 5), (129, 4), (383, 6), (640, 3), (1500, 10), (1600, 4), (200, 64), (513, 33)])
+@pytest.mark.parametrize('N,M', [(1, 1), (2, 3), (127, 2), (128, 5), (129, 4), (383, 6), (640, 3), (1500, 10), (1600, 4), (200, 64), (513, 33),
+                                 (200, 96), (300, 65), (150, 200), (700, 130)])   # M > 64: the Gram / gradient / Sobol kernels stage their panels in chunks
 def test_against_oracle(gpu, N, M):
     X, y = o.synthetic_fold(N, M, k=N % 7)
     rng = np.random.default_rng(N + M)
@@ -687,3 +688,50 @@ def test_sizes_between_the_panel_boundaries(gpu, N, M):
     assert lml == pytest.approx(ref, rel=1e-10)
     assert np.max(np.abs(grad - gref)) <= 1e-8 * np.max(np.abs(gref))
     assert lml == lml2 and np.array_equal(grad, grad2)
+
+
+def test_wide_design_other_entry_points(gpu):
+    """M = 70 > 64 beyond test_against_oracle: the gradient GP (its derivative rows loop over the dimensions), a whole fit against the
+    oracle's, all 3 M + 1 canonical Sobol slices + an arbitrary one in one pass over chunked panels, a cross-output term; the standard
+    errors say that they stop at M = 64 (the reference has no such limit: DESIGN.md section 9)."""
+    from romcomma_amd.gpr.optimize import fit_lbfgsb
+    N, M = 260, 70
+    X, y = o.synthetic_fold(N, M, k=4)
+    rng = np.random.default_rng(7)
+    ell, var, noise = rng.uniform(4.0, 12.0, M), 1.2, 0.03
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(ell, var, noise)
+    xs = o.synthetic_fold(5, M, k=33)[0]
+    mean, cov = gp.predict_gradient(xs)                      # (o, M), (o, M, o, M): V^T V, the caller applies sign and diagonal term
+    m_ref, c_ref = o.predict_gradient(X, y, ell, var, noise, xs)
+    np.testing.assert_allclose(mean, m_ref, rtol=1e-8, atol=1e-10)
+    z = xs / ell
+    kxx = var * np.exp(-0.5 * (np.sum(z * z, 1)[:, None] + np.sum(z * z, 1)[None, :] - 2.0 * z @ z.T))
+    full = -np.transpose(cov, (0, 2, 1, 3))
+    idx = np.arange(M)
+    full[:, :, idx, idx] += kxx[:, :, None] / ell[None, None, :] ** 2
+    np.testing.assert_allclose(full, c_ref, rtol=1e-7, atol=1e-9 * np.max(np.abs(c_ref)))
+    slices = o.all_slices(M) + [(9, 66)]
+    V = gp.sobol_closed(slices)
+    alpha = o.k_inv_y(X, y, ell, var, noise)
+    g, phi = o.sobol_prepare(X, alpha[None, :], np.array([var]), ell[None, :])
+    check = [0, 63, 64, 69, M + 63, M + 64, 2 * M, 2 * M + 5, 2 * M + 64, 3 * M - 1, 3 * M, 3 * M + 1]      # either side of the chunk boundary
+    Vr = o.sobol_V_pair(X, g[0], g[0], phi[0], phi[0], [slices[i] for i in check])
+    np.testing.assert_allclose(V[check], Vr, rtol=1e-7, atol=1e-10 * abs(Vr[-2]))
+    ell_j = rng.uniform(4.0, 12.0, M)
+    alpha_j = o.k_inv_y(X, np.roll(y, 3), ell_j, 0.9, 0.05)
+    gj, phij = o.sobol_prepare(X, alpha_j[None, :], np.array([0.9]), ell_j[None, :])
+    few = [(0, M), (60, 68), (0, 1)]
+    np.testing.assert_allclose(gp.sobol_cross(ell_j, 0.9, alpha_j, few), o.sobol_V_pair(X, g[0], gj[0], phi[0], phij[0], few), rtol=1e-7, atol=1e-12)
+    with pytest.raises(gpu.RcgpError, match='M <= 64'):
+        gp.sobol_error_terms([(0, 1)])
+    # a whole fit in 72 parameters: the optimum is an optimum of the ORACLE's objective too (its LML there equals the GPU's, its gradient
+    # in the unconstrained space vanishes to what L-BFGS-B's ftol leaves) -- two independent runs over so flat a surface need not meet
+    start = o.lml(X, y, 5.0 * np.ones(M), 2.0, 0.02)
+    fit = fit_lbfgsb(gp, 5.0 * np.ones(M), 2.0, 0.02)
+    assert fit['log_marginal'] > start + 10.0 and fit['nfev'] > 20
+    at_optimum, grad = o.lml_and_grad(X, y, fit['lengthscales'], fit['variance'], fit['noise'])
+    assert fit['log_marginal'] == pytest.approx(at_optimum, rel=1e-9)
+    lml_gpu, grad_gpu = gp.lml_grad()
+    np.testing.assert_allclose(grad_gpu, grad, rtol=1e-6, atol=1e-8 * np.max(np.abs(grad)))
+    gp.close()
