@@ -312,7 +312,15 @@ RC_API int rcgp_set_y(rcgp_handle h, const double* y) {
 
 // One asynchronous copy from pinned memory, no stream synchronisation: the evaluation that follows is ordered behind it on the main
 // stream. The staging block is rewritten only after the previous upload has left it (an event that has long completed by then).
-static int upload_hyper(rcgp_handle_s* h) {
+static int upload_hyper(rcgp_handle_s* h) {                     // (the values are noted; they travel with the next call that needs them)
+  h->hyper_set = true;
+  h->hyper_dirty = true;
+  h->factored = h->inverted = h->gram_fresh = false;
+  return 0;
+}
+
+static int flush_hyper(rcgp_handle_s* h) {
+  if (!h->hyper_dirty) return 0;
   const size_t LL = (size_t)h->L * h->L, LM = h->ell.size();
   if (h->hyper_in_flight) { RC_HIP(hipEventSynchronize(h->ev_hyper)); h->hyper_in_flight = false; }
   memcpy(h->pin, h->ell.data(), LM * sizeof(double));
@@ -321,8 +329,7 @@ static int upload_hyper(rcgp_handle_s* h) {
   RC_HIP(hipMemcpyAsync(h->ell_d, h->pin, (LM + 2 * LL) * sizeof(double), hipMemcpyHostToDevice, h->stream));
   RC_HIP(hipEventRecord(h->ev_hyper, h->stream));
   h->hyper_in_flight = true;
-  h->hyper_set = true;
-  h->factored = h->inverted = h->gram_fresh = false;
+  h->hyper_dirty = false;
   return 0;
 }
 
@@ -383,6 +390,7 @@ static int need_hyper(rcgp_handle_s* h) {
 
 static int do_gram(rcgp_handle_s* h) {
   int rc;
+  if ((rc = flush_hyper(h))) return rc;
   if ((rc = rc_launch_scale(h))) return rc;
   if ((rc = rc_launch_gram(h))) return rc;
   h->factored = h->inverted = false;
@@ -509,6 +517,57 @@ static int batch_check(int n, rcgp_handle* hs, const char* who) {
   return 0;
 }
 
+static int ensure_batch_buffers(rcgp_handle_s* h) {
+  if (!h->bres_d) {
+    RC_HIP(hipMalloc(&h->bres_d, (size_t)2 * RC_MAX_BATCH * RC_SCAL_ELEMS * sizeof(double)));
+    RC_HIP(hipHostMalloc(&h->bres_pin, (size_t)2 * RC_MAX_BATCH * RC_SCAL_ELEMS * sizeof(double), hipHostMallocDefault));
+  }
+  return 0;
+}
+
+__global__ void k_scatter_hyper(RcBP<double> dst, const double* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst.p[blockIdx.z][i] = src[(size_t)blockIdx.z * RC_SCAL_ELEMS + i];
+}
+
+// The new hyper-parameters of every unit of a batched call in ONE copy from pinned memory and one scatter kernel (a copy per unit
+// otherwise: with 16 small units they were a third of the operations of an evaluation). Staging: the second half of the leader's
+// batch buffers; it is repacked only after the previous upload has left it.
+static int flush_hyper_batch(rcgp_handle_s* h, const std::vector<rcgp_handle_s*>& units) {
+  std::vector<rcgp_handle_s*> dirty;
+  for (auto hu : units)
+    if (hu->hyper_dirty) dirty.push_back(hu);
+  if (dirty.size() <= 1) {
+    for (auto hu : dirty) {
+      int rc = flush_hyper(hu);
+      if (rc) { h->err = hu->err; return rc; }
+    }
+    return 0;
+  }
+  int rc;
+  if ((rc = ensure_batch_buffers(h))) return rc;
+  const int M = h->M, n = M + 2;                                   // single-output units: ell[M], then the kernel and the likelihood variance
+  double* stage_pin = h->bres_pin + (size_t)RC_MAX_BATCH * RC_SCAL_ELEMS;
+  double* stage_d = h->bres_d + (size_t)RC_MAX_BATCH * RC_SCAL_ELEMS;
+  if (h->hyper_in_flight) { RC_HIP(hipEventSynchronize(h->ev_hyper)); h->hyper_in_flight = false; }
+  RcBP<double> dst;
+  for (int k = 0; k < RC_MAX_BATCH; ++k) dst.p[k] = nullptr;
+  for (size_t k = 0; k < dirty.size(); ++k) {
+    double* row = stage_pin + k * RC_SCAL_ELEMS;
+    memcpy(row, dirty[k]->ell.data(), (size_t)M * sizeof(double));
+    row[M] = dirty[k]->Fm[0];
+    row[M + 1] = dirty[k]->Sm[0];
+    dst.p[k] = dirty[k]->ell_d;                                    // (ell, then F and Sigma: one allocation per handle)
+  }
+  RC_HIP(hipMemcpyAsync(stage_d, stage_pin, dirty.size() * RC_SCAL_ELEMS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RC_HIP(hipEventRecord(h->ev_hyper, h->stream));
+  h->hyper_in_flight = true;
+  hipLaunchKernelGGL(k_scatter_hyper, dim3((unsigned)((n + 255) / 256), 1, (unsigned)dirty.size()), dim3(256), 0, h->stream, dst, (const double*)stage_d, n);
+  RC_HIP(hipGetLastError());
+  for (auto hu : dirty) hu->hyper_dirty = false;
+  return 0;
+}
+
 // Gram + factorisation for the units that have no factor, L^-1 + alpha for those that lack them: each stage one batched schedule.
 static int batch_ensure(int n, rcgp_handle* hs, bool want_inverse) {
   int rc;
@@ -517,6 +576,7 @@ static int batch_ensure(int n, rcgp_handle* hs, bool want_inverse) {
     if (!hs[u]->factored) todo.push_back(hs[u]);
   if (!todo.empty()) {
     rcgp_handle_s* h = todo[0];
+    if ((rc = flush_hyper_batch(h, todo))) { hs[0]->err = h->err; return rc; }
     RcBatchScope scope(h, todo);
     if ((rc = rc_launch_scale(h)) || (rc = rc_launch_gram(h))) { hs[0]->err = h->err; return rc; }
     for (auto hu : todo) { hu->factored = hu->inverted = false; hu->gram_fresh = true; }
@@ -539,15 +599,12 @@ static int batch_ensure(int n, rcgp_handle* hs, bool want_inverse) {
 // ONE copy into pinned memory, ONE synchronisation. status[u] = 0 or the leading minor that failed (that unit's factor is dropped).
 static int batch_values(int n, rcgp_handle* hs, double* lml, double* grad, int* status) {
   rcgp_handle_s* h = hs[0];
-  if (!h->bres_d) {
-    RC_HIP(hipMalloc(&h->bres_d, (size_t)RC_MAX_BATCH * RC_SCAL_ELEMS * sizeof(double)));
-    RC_HIP(hipHostMalloc(&h->bres_pin, (size_t)RC_MAX_BATCH * RC_SCAL_ELEMS * sizeof(double), hipHostMallocDefault));
-  }
+  int rc;
+  if ((rc = ensure_batch_buffers(h))) return rc;
   std::vector<rcgp_handle_s*> units(hs, hs + n);
   {
     RcBatchScope scope(h, units);
-    int rc = rc_batch_lml_reduce(h);
-    if (rc) return rc;
+    if ((rc = rc_batch_lml_reduce(h))) return rc;
   }
   RC_HIP(hipMemcpyAsync(h->bres_pin, h->bres_d, (size_t)n * RC_SCAL_ELEMS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   RC_HIP(hipStreamSynchronize(h->stream));
@@ -608,6 +665,7 @@ RC_API int rcgp_stage_batch(int stage, int n, rcgp_handle* hs) {
   RcBatchScope scope(h, units);
   switch (stage) {
     case 0:
+      if ((rc = flush_hyper_batch(h, units))) return rc;
       if ((rc = rc_launch_scale(h)) || (rc = rc_launch_gram(h))) return rc;
       for (auto hu : units) { hu->factored = hu->inverted = false; hu->gram_fresh = true; }
       return 0;

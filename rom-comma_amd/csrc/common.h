@@ -125,6 +125,8 @@ struct rcgp_handle_s {
   size_t pin_elems = 0, pin_result = 0;   // (pin_result: first element of the result block)
   hipEvent_t ev_hyper = nullptr;   // the last hyper-parameter upload has left the staging buffer
   bool hyper_in_flight = false;
+  bool hyper_dirty = false;        // the host copy of the hyper-parameters is newer than the device's: uploaded by the next call that needs them
+                                   // (one copy per handle, or ONE copy + one scatter kernel for all units of a batched call: api.hip)
   // predict scratch
   double *Xs = nullptr, *Zs = nullptr, *sqs = nullptr, *KsT = nullptr, *pmean = nullptr, *pvar = nullptr;
   int64_t pred_cap = 0;        // rows of KsT / pmean / pvar
@@ -145,8 +147,8 @@ struct rcgp_handle_s {
   // batch: the units a launch covers while this handle leads a batched call (api.hip: RcBatchScope). bh[0] == this.
   int nb = 1;
   rcgp_handle_s* bh[RC_MAX_BATCH] = {};
-  double* bres_d = nullptr;    // RC_MAX_BATCH x RC_SCAL_ELEMS: the result blocks of a batched evaluation led by this handle (allocated on first use)
-  double* bres_pin = nullptr;  // ... and their pinned host copy
+  double* bres_d = nullptr;    // 2 x RC_MAX_BATCH x RC_SCAL_ELEMS: the result blocks of a batched evaluation led by this handle, then the staging
+  double* bres_pin = nullptr;  // of the units' hyper-parameters on their way up (allocated on first use); ... and their pinned host copy
   std::string err;
 };
 

@@ -751,6 +751,13 @@ static int potrf_fine(rcgp_handle_s* h) {
   return 0;
 }
 
+// w = y (the right-hand side the factorisation carries along) and status word = 0, every unit of a batch in one launch
+__global__ void k_potrf_init(RcBP<double> wb, RcBP<const double> yb, RcBP<int> infob, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) wb.p[blockIdx.z][i] = yb.p[blockIdx.z][i];
+  if (i == 0) *infob.p[blockIdx.z] = 0;
+}
+
 // Right-looking blocked Cholesky. Default: the fine-grained multi-stream schedule above. RCGP_FINE=0: one-panel look-ahead (as soon as the
 // trailing update has finished the NEXT panel's columns, that panel is factored on the chain stream while the bulk stream updates the
 // rest of the trailing matrix); RCGP_LOOKAHEAD=0 or a matrix of fewer than four blocks: strictly sequential on the main stream.
@@ -760,11 +767,17 @@ int rc_potrf(rcgp_handle_s* h) {
   h->launch = h->stream;
   h->launch_stop = nullptr;                                        // (an earlier call may have failed half-way)
   h->prof_pending = -1;
-  for (int u = 0; u < h->nb; ++u) {                               // (every unit of a batched call; h alone otherwise)
-    rcgp_handle_s* hu = (h->nb > 1) ? h->bh[u] : h;
-    RC_HIP(hipMemcpyAsync(hu->w, hu->y, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    RC_HIP(hipMemsetAsync(hu->info, 0, sizeof(int), h->stream));
-    hu->gram_fresh = false;                                        // consumed, whatever happens below
+  if (h->nb > 1) {                                                // a batched call: w = y and status = 0 for every unit in ONE launch (2 nb copies otherwise)
+    RC_BP(double, wb, h->w)
+    RC_BP(const double, yb, (const double*)h->y)
+    RC_BP(int, fb, h->info)
+    hipLaunchKernelGGL(k_potrf_init, dim3((unsigned)((Np + 255) / 256), 1, (unsigned)h->nb), dim3(256), 0, h->stream, wb, yb, fb, Np);
+    RC_HIP(hipGetLastError());
+    for (int u = 0; u < h->nb; ++u) h->bh[u]->gram_fresh = false;  // consumed, whatever happens below
+  } else {
+    RC_HIP(hipMemcpyAsync(h->w, h->y, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    RC_HIP(hipMemsetAsync(h->info, 0, sizeof(int), h->stream));
+    h->gram_fresh = false;                                         // consumed, whatever happens below
   }
   g_rc_stat[0] += h->nb;
   const bool la = h->lookahead && Np >= 4 * 128;                   // (the multi-stream schedule needs no minimum number of panels)
