@@ -384,6 +384,18 @@ class HipGP(GPR):
             self._unit_signature[slot] = signature
         return gp
 
+    def _factor_outputs(self) -> None:
+        """With one unit per output: factor (and invert) every output that needs it in ONE batched schedule (``rcgp_factor_batch``) --
+        a model read back from disk (``run.gsa``) otherwise pays L factorisations one after the other when its K_inv_Y is first asked
+        for (the reference: two Cholesky factorisations per output and GSA kind, gsa/calibrators.py:126-127)."""
+        if self._is_covariant or self._L < 2 or self.pool_size < self._L:
+            return
+        units = [self._select(l) for l in range(self._L)]
+        status = _lib.factor_batch(units)
+        for l, k in enumerate(status):
+            if k > 0:
+                raise _lib.NotPositiveDefiniteError(int(k), f'output {l}: matrix is not positive definite: leading minor {int(k)}')
+
     @property
     def implementation(self) -> Tuple[Any, ...]:
         """One (output index, hyper-parameter record) pair per independent output; the device handles are a pool (``pool_size``)."""
@@ -590,6 +602,7 @@ class HipGP(GPR):
         """(L,1,N): alpha_l = (K_l + noise_l I)^-1 y_l (gpr/models.py:441-444); covariant: the (LN) solve reshaped."""
         if self._is_covariant:
             return self._select_mo().k_inv_y()
+        self._factor_outputs()
         return np.stack([self._select(l).k_inv_y() for l, _ in self.implementation])[:, None, :]
 
     def check_K_inv_Y(self, x: np.ndarray) -> np.ndarray:

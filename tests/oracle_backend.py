@@ -94,8 +94,20 @@ def lml_grad_batch(gps):
     return lml, grad, status
 
 
+def factor_batch(gps):
+    """Stand-in for ``_lib.factor_batch``: nothing to cache on the CPU; status 1 where the matrix is not positive definite."""
+    status = np.zeros(len(gps), dtype=np.int32)
+    for u, gp in enumerate(gps):
+        try:
+            gp.lml()
+        except np.linalg.LinAlgError:
+            status[u] = 1
+    return status
+
+
 def install():
     from romcomma_amd import _lib
     _lib.RcGP = OracleGP
     _lib.lml_grad_batch = lml_grad_batch
+    _lib.factor_batch = factor_batch
     _lib.device_count = lambda: 1
