@@ -80,6 +80,7 @@ class ClosedSobol(Calibrator):
             self.is_F_diagonal, self.is_gp_covariant = True, False
             self.F, self.Lambda, self.K_inv_Y = gp.F, gp.Lambda, gp.K_inv_Y
             self.owned = list(gp.owned_outputs)
+            self._share_cache()
             self._calibrate()
             return
         self.owned = list(range(self.L))
@@ -96,7 +97,22 @@ class ClosedSobol(Calibrator):
             self.F = F.reshape(self.L, self.L)
         self.Lambda = np.broadcast_to(np.asarray(gp.kernel.data.frames.lengthscales.np, dtype=np.float64), (self.L, self.M)).copy()
         self.K_inv_Y = np.asarray(gp.K_inv_Y, dtype=np.float64).reshape(self.L, self.N)          # also leaves each alpha cached on host
+        self._share_cache()
         self._calibrate()
+
+    def _share_cache(self):
+        """The conditional variances depend on (F, Lambda, K_inv_Y) only, and ONE device pass yields the slices of all three GSA kinds: the
+        calibrators that ``run.gsa`` builds for 'first_order', 'closed' and 'total' on one gp (the reference builds -- and recomputes -- one
+        per kind, gsa/models.py:205, user/run.py:141-147) share the memo through the gp, keyed by the values it was computed from."""
+        signature = (self.is_F_diagonal, np.asarray(self.F).tobytes(), np.asarray(self.Lambda).tobytes(), np.asarray(self.K_inv_Y).tobytes())
+        shared = getattr(self.gp, '_sobol_memo', None)
+        if shared is None or shared[0] != signature:
+            shared = (signature, {})
+            try:
+                self.gp._sobol_memo = shared
+            except AttributeError:                          # (an object that takes no attributes: keep the memo to this calibrator)
+                pass
+        self._cache = shared[1]
 
     # ---- device calls
     def _V_many(self, slices: Sequence[Sequence[int]]) -> np.ndarray:
