@@ -93,8 +93,8 @@ int rcgp_sobol_cross(rcgp_handle h, const double* ell_j, double var_j, const dou
  * a == b entries the reference applies (:281, :284, :322):
  *   phi_d = mu_phi_mu term of the DIAGONAL rank equations (:259-288), psi_d = |psi_factor_ab|^2 (:311-322),
  *   phi_m, psi_m = the same under the MIXED rank equation (used when is_T_partial is false).
- * The caller assembles W = (phi - psi) + transpose and T (:324-346). Requires rcgp_factor. M <= 64 (returns -2 beyond; beyond M = 29 the
- * canonical slices take several passes: their column accumulators no longer fit in LDS together). */
+ * The caller assembles W = (phi - psi) + transpose and T (:324-346). Requires rcgp_factor. Beyond M = 29 the canonical
+ * slices take several passes (their column accumulators no longer fit in LDS together); beyond M = 64 the inputs pass through LDS in chunks. */
 int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var_a, const double* alpha_a, int n_slices, const int32_t* slices,
                            double* phi_d, double* psi_d, double* phi_m, double* psi_m);
 

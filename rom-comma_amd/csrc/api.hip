@@ -261,8 +261,8 @@ static int create_impl(rcgp_handle_s* h, const double* X, const double* y) {
 RC_API int rcgp_create_mo(rcgp_handle* out, int device, int64_t N, int M, int L, const double* X, const double* Y) {
   if (!out) return -1;
   *out = nullptr;
-  if (N < 1 || M < 1 || M > (L == 1 ? RC_MAX_M_WIDE : RC_MAX_M) || L < 1 || L > RC_MAX_L || !X || !Y) {
-    g_create_error = "rcgp_create: bad argument (need N>=1, 1<=M<=256 for one output and <=64 for a covariant GP, 1<=L<=16, X, y)";
+  if (N < 1 || M < 1 || M > RC_MAX_M_WIDE || L < 1 || L > RC_MAX_L || !X || !Y) {
+    g_create_error = "rcgp_create: bad argument (need N>=1, 1<=M<=256, 1<=L<=16, X, y)";
     return -2;
   }
   int ndev = 0;
@@ -1009,7 +1009,6 @@ RC_API int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var
   if (ell_a)
     for (int m = 0; m < h->M; ++m)
       if (!(ell_a[m] > 0.0)) { h->err = "rcgp_sobol_error_terms: lengthscales must be positive"; return -2; }
-  if (h->M > RC_MAX_M) { h->err = "rcgp_sobol_error_terms: the standard errors are limited to M <= 64 input dimensions"; return -2; }
   int rc;
   if ((rc = rcgp_factor(h))) return rc;
   return rc_sobol_error_terms(h, ell_a, var_a, alpha_a, n_slices, slices, phi_d, psi_d, phi_m, psi_m);

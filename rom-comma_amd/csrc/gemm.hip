@@ -1001,13 +1001,15 @@ int rc_launch_grad(rcgp_handle_s* h, int* nrows) {
 //   [2M + 1]  sum W over the elements with equal in-block index   (d LML / d Sigma)
 // rc_grad_finish_mo adds the tiles of every block pair and applies the factors.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int LZ, int WN>
+// WIDE (M > RC_MAX_M = 64): Z chunks of LZ - 1 = 32 dimensions per 16-row group, as in k_grad<., ., WIDE>.
+template <int LZ, int WN, bool WIDE = false>
 __global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t ld, int64_t Np, int64_t N, int M,
                                         const double* __restrict__ Z, const double* __restrict__ sq, const double* __restrict__ alpha,
                                         const double* __restrict__ FS, int L, int tb, double* __restrict__ partial) {
   constexpr int ZL = 2 * 128 * LZ;
   constexpr int NW = 2 * WN;
-  constexpr int RW = 2 * RC_MAX_M + 2;
+  constexpr int RW = 2 * (WIDE ? RC_MAX_M_WIDE : RC_MAX_M) + 2;
+  constexpr int MCH = LZ - 1;                                 // WIDE: dimensions staged at a time
   constexpr int ZA = ZL + 4 * 128;                            // + alpha and sq of the tile's 128 rows and 128 columns
   __shared__ double lds[(GEMM_LDS > ZA ? GEMM_LDS : ZA) + NW * RW];
   int ti, tj;
@@ -1020,11 +1022,14 @@ __global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t
   double* zj = lds + 128 * LZ;
   double* ars = lds + ZL;                                     // alpha_i[128], sq_i[128], alpha_j[128], sq_j[128]
   double* red = lds + (GEMM_LDS > ZA ? GEMM_LDS : ZA);
-  for (int e = threadIdx.x; e < 128 * M; e += 128 * WN) {
-    const int rr = e / M, m = e - rr * M;
-    zi[rr * LZ + m] = Z[((int64_t)ti * 128 + rr) * M + m];
-    zj[rr * LZ + m] = Z[((int64_t)tj * 128 + rr) * M + m];
-  }
+  auto stage_z = [&](int c0, int mc) {                        // dimensions [c0, c0 + mc) of the tile's Z rows and columns
+    for (int e = threadIdx.x; e < 128 * mc; e += 128 * WN) {
+      const int rr = e / mc, m = e - rr * mc;
+      zi[rr * LZ + m] = Z[((int64_t)ti * 128 + rr) * M + c0 + m];
+      zj[rr * LZ + m] = Z[((int64_t)tj * 128 + rr) * M + c0 + m];
+    }
+  };
+  if constexpr (!WIDE) stage_z(0, M);
   if (threadIdx.x < 128) {                                    // (through LDS: no 64-bit address arithmetic per element in the epilogue)
     ars[threadIdx.x] = alpha[(int64_t)ti * 128 + threadIdx.x];
     ars[128 + threadIdx.x] = sq[(int64_t)ti * 128 + threadIdx.x];
@@ -1055,17 +1060,31 @@ __global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t
       for (int ni = 0; ni < NI_; ++ni) dot[r][ni] = 0.0;
     int mcount = M;
     asm volatile("" : "+s"(mcount), "+v"(ge));
+    auto dot_over = [&](int mc) {
 #pragma unroll 1
-    for (int m = 0; m < mcount; ++m) {
-      double zr[4], zc[NI_];
+      for (int m = 0; m < mc; ++m) {
+        double zr[4], zc[NI_];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zr[r] = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
+        for (int r = 0; r < 4; ++r) zr[r] = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
 #pragma unroll
-      for (int ni = 0; ni < NI_; ++ni) zc[ni] = zj[(wc_ + 16 * ni + fr_) * LZ + m];
+        for (int ni = 0; ni < NI_; ++ni) zc[ni] = zj[(wc_ + 16 * ni + fr_) * LZ + m];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int ni = 0; ni < NI_; ++ni) dot[r][ni] = fma(zr[r], zc[ni], dot[r][ni]);
+          for (int ni = 0; ni < NI_; ++ni) dot[r][ni] = fma(zr[r], zc[ni], dot[r][ni]);
+      }
+    };
+    if constexpr (!WIDE) {
+      dot_over(mcount);
+    } else {
+#pragma unroll 1
+      for (int c0 = 0; c0 < mcount; c0 += MCH) {
+        const int mc = (mcount - c0 < MCH) ? mcount - c0 : MCH;
+        __syncthreads();                                       // (everybody has read the chunk staged before)
+        stage_z(c0, mc);
+        __syncthreads();
+        dot_over(mc);
+      }
     }
     double wk[4][NI_];
 #pragma unroll
@@ -1088,26 +1107,40 @@ __global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t
         if (ii == jj) gdiag += wgt * wij;
       }
     }
+    auto sums_over = [&](int c0, int mc) {                     // the sums of the mc dimensions in LDS (dimension c0 + m)
 #pragma unroll 1
-    for (int m = 0; m < mcount; ++m) {
-      double ga = 0.0, gb = 0.0;
+      for (int m = 0; m < mc; ++m) {
+        double ga = 0.0, gb = 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double zim = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
+        for (int r = 0; r < 4; ++r) {
+          const double zim = zi[(wr_ + 16 * mi + 4 * r + fq_) * LZ + m];
 #pragma unroll
-        for (int ni = 0; ni < NI_; ++ni) {
-          const double zjm = zj[(wc_ + 16 * ni + fr_) * LZ + m];
-          const double d = zim - zjm;
-          const double wd = wk[r][ni] * d;
-          ga = fma(wd, same ? d : zim, ga);
-          gb = fma(wd, same ? 0.0 : zjm, gb);
+          for (int ni = 0; ni < NI_; ++ni) {
+            const double zjm = zj[(wc_ + 16 * ni + fr_) * LZ + m];
+            const double d = zim - zjm;
+            const double wd = wk[r][ni] * d;
+            ga = fma(wd, same ? d : zim, ga);
+            gb = fma(wd, same ? 0.0 : zjm, gb);
+          }
+        }
+        ga = wave_sum(ga);
+        gb = wave_sum(gb);
+        if (lane_ == 0) {
+          red[wave_ * RW + c0 + m] += ga;
+          red[wave_ * RW + M + c0 + m] += gb;
         }
       }
-      ga = wave_sum(ga);
-      gb = wave_sum(gb);
-      if (lane_ == 0) {
-        red[wave_ * RW + m] += ga;
-        red[wave_ * RW + M + m] += gb;
+    };
+    if constexpr (!WIDE) {
+      sums_over(0, mcount);
+    } else {
+#pragma unroll 1
+      for (int c0 = 0; c0 < mcount; c0 += MCH) {
+        const int mc = (mcount - c0 < MCH) ? mcount - c0 : MCH;
+        __syncthreads();
+        stage_z(c0, mc);
+        __syncthreads();
+        sums_over(c0, mc);
       }
     }
   }
@@ -1118,8 +1151,7 @@ __global__ void RC_BOUNDS(WN) k_grad_mo(const double* __restrict__ Linv, int64_t
     red[wave_ * RW + 2 * M + 1] = gdiag;
   }
   __syncthreads();
-  if (threadIdx.x < 2 * M + 2) {
-    const int m = threadIdx.x;
+  for (int m = threadIdx.x; m < 2 * M + 2; m += 128 * WN) {     // (one pass up to M = 64)
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) s += red[w * RW + m];
@@ -1138,9 +1170,12 @@ int rc_launch_grad_mo(rcgp_handle_s* h, int* nrows) {
   if (h->M <= 32)
     hipLaunchKernelGGL((k_grad_mo<33, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
                        h->sq, h->alpha, h->FS_d, h->L, tb, h->partial);
-  else
+  else if (h->M <= RC_MAX_M)
     hipLaunchKernelGGL((k_grad_mo<65, RC_WN>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M, h->Z,
                        h->sq, h->alpha, h->FS_d, h->L, tb, h->partial);
+  else
+    hipLaunchKernelGGL((k_grad_mo<33, RC_WN, true>), dim3((unsigned)nb), dim3(128 * RC_WN), 0, h->launch, h->Linv, h->Np, h->Np, h->N, h->M,
+                       h->Z, h->sq, h->alpha, h->FS_d, h->L, tb, h->partial);
   RC_HIP(hipGetLastError());
   *nrows = (int)nb;
   return 0;

@@ -477,21 +477,45 @@ int rc_sobol_pair(rcgp_handle_s* h, const double* phi_a, double pre_a, const dou
 //         window [s_lo, s_hi), nS = s_hi - s_lo: all 3M in one pass when the column accumulators fit in LDS (M <= 29), otherwise the host
 //         walks the window over the 3M indices (the running exponent sums are rebuilt every pass, exponentials only where wanted);
 // mode 1: ONE arbitrary slice [ma, mb) (ClosedSobolWithError.marginalize takes any, gsa/calibrators.py:348-373), nS = 1.
+// WIDE (M > RC_MAX_M = 64): the X panels pass through LDS in chunks of 64 dimensions as in k_sobol_pairs<., WIDE> (the running exponent sums
+// live in registers; a chunk is staged when the walk enters it). The fast instantiation is the kernel as it was.
+template <bool WIDE = false>
 __global__ void __launch_bounds__(256) k_sobol_matvec(const double* __restrict__ X, const double* __restrict__ gl,
                                                       const double* __restrict__ consts, int M, int64_t Np, double* __restrict__ partial,
                                                       int mode, int ma, int mb, int s_lo, int s_hi) {
   extern __shared__ double sm[];
-  double* xi = sm;                        // [M][XST] rows (N side)
-  double* xj = sm + M * XST;              // [M][XST] columns (n side)
-  double* slots = xj + M * XST;           // [4 waves][2 kinds][128]
+  const int MC = WIDE ? RC_MAX_M : M;
+  double* xi = sm;                        // [MC][XST] rows (N side)
+  double* xj = sm + MC * XST;             // [MC][XST] columns (n side)
+  double* slots = xj + MC * XST;          // [4 waves][2 kinds][128]
   double* colacc = slots + 4 * 2 * 128;   // [nS][128]
   const int nS = s_hi - s_lo;
   const int tj = blockIdx.x, ti = blockIdx.y;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int e = t; e < 128 * M; e += 256) {
-    const int rr = e / M, m = e - rr * M;
-    xi[m * XST + rr] = X[((int64_t)ti * 128 + rr) * M + m];
-    xj[m * XST + rr] = X[((int64_t)tj * 128 + rr) * M + m];
+  int cb = 0;                             // first dimension of the chunk in LDS (stays 0 on the fast path)
+  bool staged = !WIDE;
+  auto enter = [&](int m) {               // WIDE: make the chunk of dimension m resident (every thread, at the same points of uniform loops)
+    if constexpr (WIDE) {
+      const int c0 = (m / MC) * MC;
+      if (staged && c0 == cb) return;
+      __syncthreads();                    // (everybody has read the chunk staged before)
+      cb = c0;
+      staged = true;
+      const int mc = (M - c0 < MC) ? M - c0 : MC;
+      for (int e = t; e < 128 * mc; e += 256) {
+        const int rr = e / mc, mm = e - rr * mc;
+        xi[mm * XST + rr] = X[((int64_t)ti * 128 + rr) * M + c0 + mm];
+        xj[mm * XST + rr] = X[((int64_t)tj * 128 + rr) * M + c0 + mm];
+      }
+      __syncthreads();
+    }
+  };
+  if constexpr (!WIDE) {
+    for (int e = t; e < 128 * M; e += 256) {
+      const int rr = e / M, m = e - rr * M;
+      xi[m * XST + rr] = X[((int64_t)ti * 128 + rr) * M + m];
+      xj[m * XST + rr] = X[((int64_t)tj * 128 + rr) * M + m];
+    }
   }
   for (int e = t; e < nS * 128; e += 256) colacc[e] = 0.0;
   const int tx = t & 15, ty = t >> 4;
@@ -542,17 +566,18 @@ __global__ void __launch_bounds__(256) k_sobol_matvec(const double* __restrict__
 
   // one m-step of the running exponent sums; cf / cc receive sum_rows gi exp(t_m) / gi exp(e) where wanted
   auto step = [&](int m, bool want_f, bool want_c, double (&cf)[8], double (&cc)[8]) {
+    enter(m);
     const double k0 = c0[m], k2 = c2[m], kl = pl[m], kj = pj[m];
     double ai[8], ui[8], bj[8], xc[8];
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      const double x = xi[m * XST + ty + 16 * a];
+      const double x = xi[(m - cb) * XST + ty + 16 * a];
       ai[a] = fma(kl * x, x, k0);
       ui[a] = k2 * x;
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const double2 x = *reinterpret_cast<const double2*>(xj + m * XST + 2 * tx + 32 * b);
+      const double2 x = *reinterpret_cast<const double2*>(xj + (m - cb) * XST + 2 * tx + 32 * b);
       xc[2 * b] = x.x;
       xc[2 * b + 1] = x.y;
       bj[2 * b] = kj * x.x * x.x;
@@ -740,14 +765,18 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
     }
   };
   const int64_t nblk = T * T;
-  const size_t lds_pairs = (size_t)(2 * M * XST + 4 * 3 * M) * sizeof(double);
+  const bool wide = M > RC_MAX_M;                                 // X panels in chunks of 64 dimensions (k_sobol_pairs / k_sobol_matvec <., WIDE>)
+  const int Mc = wide ? RC_MAX_M : M;
+  const size_t lds_pairs = (size_t)(2 * Mc * XST + 4 * 3 * M) * sizeof(double);
   // canonical slices per k_sobol_matvec pass: as many column accumulators (1 KB each) as fit beside the two X panels in 160 KB of LDS
   // -- all 3M for M <= 29, 18 at M = 64
-  const size_t lds_mv_fixed = (size_t)(2 * M * XST + 4 * 2 * 128) * sizeof(double);
+  const size_t lds_mv_fixed = (size_t)(2 * Mc * XST + 4 * 2 * 128) * sizeof(double);
   const int mv_window = (int)std::min<size_t>((size_t)3 * M, (160 * 1024 - 512 - lds_mv_fixed) / (128 * sizeof(double)));
   const size_t lds_mv = lds_mv_fixed + (size_t)mv_window * 128 * sizeof(double);
-  RC_HIP(hipFuncSetAttribute((const void*)k_sobol_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
-  RC_HIP(hipFuncSetAttribute((const void*)k_sobol_matvec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mv));
+  const auto pairs_kernel = wide ? k_sobol_pairs<false, true> : k_sobol_pairs<false, false>;
+  const auto matvec_kernel = wide ? k_sobol_matvec<true> : k_sobol_matvec<false>;
+  RC_HIP(hipFuncSetAttribute((const void*)pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
+  RC_HIP(hipFuncSetAttribute((const void*)matvec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mv));
   const double pairs = (double)h->N * (double)h->N;
   double* out_d = sums_d + 8;                                   // not used (reductions write into small scratch below)
   (void)out_d;
@@ -758,7 +787,7 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
     RC_HIP(hipMemcpyAsync(consts_d, c.data(), (size_t)4 * M * sizeof(double), hipMemcpyHostToDevice, h->stream));
     {
       RcProfScope ps(h, RC_K_SOBOL, pairs * (double)(3 * M - 1));
-      hipLaunchKernelGGL(k_sobol_pairs<false>, dim3((unsigned)T, (unsigned)T), dim3(256), lds_pairs, h->stream, h->X, gl, gj, consts_d, M, 0, 0,
+      hipLaunchKernelGGL(pairs_kernel, dim3((unsigned)T, (unsigned)T), dim3(256), lds_pairs, h->stream, h->X, gl, gj, consts_d, M, 0, 0,
                          M, h->partial);
       RC_HIP(hipGetLastError());
     }
@@ -776,7 +805,7 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
     RC_HIP(hipMemcpyAsync(consts_d, c.data(), (size_t)4 * M * sizeof(double), hipMemcpyHostToDevice, h->stream));
     {
       RcProfScope ps(h, RC_K_SOBOL, pairs);
-      hipLaunchKernelGGL(k_sobol_pairs<false>, dim3((unsigned)T, (unsigned)T), dim3(256), lds_pairs, h->stream, h->X, gl, gj, consts_d, M, 1, ma,
+      hipLaunchKernelGGL(pairs_kernel, dim3((unsigned)T, (unsigned)T), dim3(256), lds_pairs, h->stream, h->X, gl, gj, consts_d, M, 1, ma,
                          mb, h->partial);
       RC_HIP(hipGetLastError());
     }
@@ -795,7 +824,7 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
       const int s_hi = std::min(3 * M, s_lo + mv_window), nS = s_hi - s_lo;
       {
         RcProfScope ps(h, RC_K_SOBOL, pairs * (double)nS);
-        hipLaunchKernelGGL(k_sobol_matvec, dim3((unsigned)T, (unsigned)T), dim3(256), lds_mv, h->stream, h->X, gl, consts_d, M, Np, h->partial, 0, 0,
+        hipLaunchKernelGGL(matvec_kernel, dim3((unsigned)T, (unsigned)T), dim3(256), lds_mv, h->stream, h->X, gl, consts_d, M, Np, h->partial, 0, 0,
                            M, s_lo, s_hi);
         RC_HIP(hipGetLastError());
       }
@@ -812,7 +841,7 @@ int rc_sobol_error_terms(rcgp_handle_s* h, const double* ell_a, double var_a, co
     RC_HIP(hipMemcpyAsync(consts_d, c.data(), (size_t)4 * M * sizeof(double), hipMemcpyHostToDevice, h->stream));
     {
       RcProfScope ps(h, RC_K_SOBOL, pairs);
-      hipLaunchKernelGGL(k_sobol_matvec, dim3((unsigned)T, (unsigned)T), dim3(256), lds_mv, h->stream, h->X, gl, consts_d, M, Np, h->partial, 1, ma,
+      hipLaunchKernelGGL(matvec_kernel, dim3((unsigned)T, (unsigned)T), dim3(256), lds_mv, h->stream, h->X, gl, consts_d, M, Np, h->partial, 1, ma,
                          mb, 0, 1);
       RC_HIP(hipGetLastError());
     }

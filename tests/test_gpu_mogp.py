@@ -223,6 +223,71 @@ def test_many_input_dimensions():
         assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('N,M,L', [(150, 70, 2), (131, 130, 3), (260, 65, 2)])
+def test_wide_designs(N, M, L):
+    """M > 64: k_gram<., WIDE> under the block structure and k_grad_mo<33, ., WIDE> (Z chunks of 32 dimensions per 16-row group, 2 M + 2
+    sums per tile written in more than one pass of the workgroup at M = 130 with 512 threads ... 262 > 256), the joint prediction."""
+    from oracle import mogp_oracle as mo
+    from romcomma_amd import _lib
+    X, Y, ell, F, S = _case(N, M, L, seed=29)
+    ell = ell * np.sqrt(M)
+    v, dF, dell, dS = mo.lml_and_grad(X, Y, ell, F, S)
+    Xs = np.random.default_rng(2).standard_normal((9, M))
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, S)
+        K = gp.gram()
+        Kref = mo.noisy_gram(X, ell, F, S)
+        assert np.abs(K - Kref).max() <= 1e-13 * np.abs(Kref).max()
+        lml, gF, gell, gS = gp.lml_grad()
+        mean, sd = gp.predict(Xs, True)
+    assert lml == pytest.approx(v, rel=1e-10)
+    for got, ref in ((gF, dF), (gell, dell), (gS, dS)):
+        assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
+    m_ref, s_ref = mo.predict(X, Y, ell, F, S, Xs, True)
+    assert np.allclose(mean, m_ref, rtol=1e-8, atol=1e-10) and np.allclose(sd, s_ref, rtol=1e-7, atol=1e-10)
+
+
+def test_wide_design_standard_error_terms():
+    """rcgp_sobol_error_terms_mo at M = 70 (diagonal F): the pair forms and matvecs over chunked X panels, the psi vectors embedded in
+    their output block of the (L N) system -- against the reduced-form oracle's pieces with the joint Cholesky factor."""
+    import scipy.linalg
+    from oracle import mogp_oracle as mo
+    from oracle import sobol_error_oracle as e
+    from romcomma_amd import _lib
+    N, M, L = 150, 70, 2
+    X, Y, ell, F, S = _case(N, M, L, seed=31)
+    X = X / 3.0
+    ell = ell * 4.0
+    F = np.diag(np.diag(F))
+    KiY = mo.k_inv_y(X, Y, ell, F, S)
+    Kc = mo.k_cho(X, ell, F, S)
+    ref = e.ClosedSobolWithErrorOracle(X, KiY.reshape(L, 1, N), np.diag(F)[None, :], ell, np.stack([np.eye(N)] * L), is_T_partial=False)     # (its own W is not used)
+    slices = [(0, 1), (63, 64), (64, 65), (0, 65), (0, M), (64, M), (1, M), (30, 69), (5, 5)]
+
+    def psi(a, b, sl):
+        H = e._pair_matrix(X, e.error_coefficients(ref.phi[a], ref.phi[b], ref.ups[b], 'H'), sl)
+        f = np.zeros(L * N)
+        f[b * N:(b + 1) * N] = ref.g0[b] * (H.T @ ref.g[a])
+        return scipy.linalg.solve_triangular(Kc, f, lower=True, check_finite=False)
+
+    with _lib.RcMOGP(X, Y) as gp:
+        gp.set_hyper(ell, F, S)
+        for a in range(L):
+            for b in range(L):
+                got = gp.sobol_error_terms(slices, a, b)
+                psi_full = psi(b, b, (0, M))
+                for s, sl in enumerate(slices):
+                    if sl[0] == sl[1]:
+                        want = (0.0, 0.0, 0.0, 0.0)
+                    else:
+                        phi_d, _, phi_m, _ = e.error_terms_pair(X, a, b, ref.g0, ref.g, ref.phi, ref.ups, ref.pre,
+                                                                [np.eye(N)] * L, sl)
+                        p = psi(a, b, sl)
+                        want = (phi_d, p @ p, phi_m, psi_full @ p)
+                    for k in range(4):
+                        assert got[k][s] == pytest.approx(want[k], rel=1e-6, abs=1e-12 * abs(want[0]) + 1e-15), (a, b, sl, k)
+
+
 def test_full_size_properties():
     """L N = 16384 (two outputs of N = 8192, M = 10), where the oracle is out of reach: size-independent properties.
     (1) With diagonal F and Sigma the joint system is block diagonal: LML, gradients and K_inv_Y must be those of the two independent

@@ -692,8 +692,8 @@ def test_sizes_between_the_panel_boundaries(gpu, N, M):
 
 def test_wide_design_other_entry_points(gpu):
     """M = 70 > 64 beyond test_against_oracle: the gradient GP (its derivative rows loop over the dimensions), a whole fit against the
-    oracle's, all 3 M + 1 canonical Sobol slices + an arbitrary one in one pass over chunked panels, a cross-output term; the standard
-    errors say that they stop at M = 64 (the reference has no such limit: DESIGN.md section 9)."""
+    oracle's, all 3 M + 1 canonical Sobol slices + an arbitrary one in one pass over chunked panels, a cross-output term, the
+    ingredients of the standard errors for the output itself and for an output pair."""
     from romcomma_amd.gpr.optimize import fit_lbfgsb
     N, M = 260, 70
     X, y = o.synthetic_fold(N, M, k=4)
@@ -723,8 +723,21 @@ def test_wide_design_other_entry_points(gpu):
     gj, phij = o.sobol_prepare(X, alpha_j[None, :], np.array([0.9]), ell_j[None, :])
     few = [(0, M), (60, 68), (0, 1)]
     np.testing.assert_allclose(gp.sobol_cross(ell_j, 0.9, alpha_j, few), o.sobol_V_pair(X, g[0], gj[0], phi[0], phij[0], few), rtol=1e-7, atol=1e-12)
-    with pytest.raises(gpu.RcgpError, match='M <= 64'):
-        gp.sobol_error_terms([(0, 1)])
+    # the standard errors' ingredients over chunked panels (k_sobol_pairs<false, WIDE>, k_sobol_matvec<WIDE>: 18 column accumulators per
+    # pass beside two 64-dimension panels): slices either side of the chunk boundary, an arbitrary one across it, and a second output
+    from oracle import sobol_error_oracle as e
+    ell2 = np.stack([ell, ell_j])
+    F2, noise2 = np.array([var, 0.9]), np.array([noise, 0.05])
+    Y2 = np.stack([y, np.roll(y, 3)], 1)
+    alpha2 = np.stack([alpha, alpha_j])
+    Kc2 = np.stack([o.k_cho(X, ell2[l], F2[l], noise2[l]) for l in range(2)])
+    ref = e.ClosedSobolWithErrorOracle(X, alpha2[:, None, :], F2[None, :], ell2, Kc2, is_T_partial=False)
+    err_slices = [(0, 1), (63, 64), (64, 65), (0, 64), (0, 65), (0, M), (64, M), (63, M), (M - 1, M), (60, 68), (M, M)]
+    for a, got in ((0, gp.sobol_error_terms(err_slices)), (1, gp.sobol_error_terms(err_slices, ell_j, 0.9, alpha_j))):
+        for s, sl in enumerate(err_slices):
+            want = (0.0, 0.0, 0.0, 0.0) if sl[0] == sl[1] else e.error_terms_pair(X, a, 0, ref.g0, ref.g, ref.phi, ref.ups, ref.pre, Kc2, sl)
+            for k in range(4):
+                assert got[k][s] == pytest.approx(want[k], rel=1e-6, abs=1e-12 * abs(want[0]) + 1e-15), (a, sl, k)
     # a whole fit in 72 parameters: the optimum is an optimum of the ORACLE's objective too (its LML there equals the GPU's, its gradient
     # in the unconstrained space vanishes to what L-BFGS-B's ftol leaves) -- two independent runs over so flat a surface need not meet
     start = o.lml(X, y, 5.0 * np.ones(M), 2.0, 0.02)
