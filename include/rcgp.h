@@ -105,6 +105,7 @@ int rcgp_sobol_error_terms(rcgp_handle h, const double* ell_a, double var_a, con
  * rcgp_lml, rcgp_factor, rcgp_get_k_inv_y (L*N values = the reference's (L,1,N)), rcgp_get_k_cho / rcgp_get_gram ((L*N)^2),
  * rcgp_set_y (Y as N x L) and the stage / profiling entries work on such a handle; the single-output entries
  * (rcgp_set_hyper, rcgp_lml_grad, rcgp_predict, rcgp_predict_gradient, rcgp_sobol_closed/cross/error_terms) return -2. */
+/* 1 <= M <= 256, 1 <= L <= 64. */
 int rcgp_create_mo(rcgp_handle* out, int device, int64_t N, int M, int L, const double* X /* N x M */, const double* Y /* N x L */);
 /* ell (L x M), F and Sigma (L x L, symmetric; diag(F) > 0). */
 int rcgp_set_hyper_mo(rcgp_handle h, const double* ell, const double* F, const double* Sigma);

@@ -262,7 +262,7 @@ RC_API int rcgp_create_mo(rcgp_handle* out, int device, int64_t N, int M, int L,
   if (!out) return -1;
   *out = nullptr;
   if (N < 1 || M < 1 || M > RC_MAX_M_WIDE || L < 1 || L > RC_MAX_L || !X || !Y) {
-    g_create_error = "rcgp_create: bad argument (need N>=1, 1<=M<=256, 1<=L<=16, X, y)";
+    g_create_error = "rcgp_create: bad argument (need N>=1, 1<=M<=256, 1<=L<=64, X, y)";
     return -2;
   }
   int ndev = 0;

@@ -14,7 +14,7 @@
                                // GP and of the Sobol standard errors
 #define RC_MAX_M_WIDE 256      // largest input dimensionality of a single-output handle: beyond RC_MAX_M the Gram, gradient and Sobol kernels stage
                                // their panels chunk by chunk (k_gram in chunks of 64 dimensions, k_grad<.., WIDE> of 32, k_sobol_pairs of 64)
-#define RC_MAX_L 16            // most outputs of one covariant GP
+#define RC_MAX_L 64            // most outputs of one covariant GP (a bound on the arguments only: nothing is sized by it)
 #define RC_SCAL_ELEMS 512      // h->scal: [0,2) LML sums, [RC_SCAL_INFO] the Cholesky status word, [8, 8+M+2) gradient sums
 #define RC_SCAL_INFO 4
 #ifndef RC_TRTRI_HALF_TILES

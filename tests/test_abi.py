@@ -55,7 +55,7 @@ def test_bad_arguments_rejected_before_touching_a_device():
     assert lib.rcgp_create(ctypes.byref(h), 0, 0, 2, dp(x), dp(y)) == -2          # N < 1
     assert lib.rcgp_create(ctypes.byref(h), 0, 4, 257, dp(x), dp(y)) == -2        # M > 256
     assert lib.rcgp_create_mo(ctypes.byref(h), 0, 4, 257, 2, dp(x), dp(x)) == -2  # M > 256, covariant
-    assert lib.rcgp_create_mo(ctypes.byref(h), 0, 4, 2, 17, dp(x), dp(x)) == -2   # L > 16
+    assert lib.rcgp_create_mo(ctypes.byref(h), 0, 4, 2, 65, dp(x), dp(x)) == -2   # L > 64
     assert lib.rcgp_create(ctypes.byref(h), 0, 4, 0, dp(x), dp(y)) == -2          # M < 1
     assert b'bad argument' in lib.rcgp_last_error(None)
     assert lib.rcgp_destroy(None) == -1

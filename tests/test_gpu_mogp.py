@@ -36,7 +36,7 @@ def test_gram_factor_and_alpha(N, M, L):
         assert gp.lml() == pytest.approx(mo.lml(X, Y, ell, F, S), rel=1e-11)
 
 
-@pytest.mark.parametrize('N,M,L', [(200, 3, 2), (130, 4, 3), (700, 5, 2)])
+@pytest.mark.parametrize('N,M,L', [(200, 3, 2), (130, 4, 3), (700, 5, 2), (60, 3, 20), (130, 2, 9)])      # (L = 9: the reference's sweep; 20 > round 3's 16)
 def test_lml_gradient(N, M, L):
     from oracle import mogp_oracle as mo
     from romcomma_amd import _lib
