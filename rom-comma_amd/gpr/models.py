@@ -250,6 +250,25 @@ def default_units_per_gpu(N: int) -> int:
     return 16 if padded <= 4096 else (4 if padded <= 12288 else 2)
 
 
+class _PoolSlots:
+    """The handles of a ``HipGP`` pool dealt to more outputs than there are handles: output ``u`` gets a free slot when its fit starts
+    (``bind``: the slot's handle with the output's targets loaded) and gives it back when the fit has ended (``release``)."""
+
+    def __init__(self, gp: 'HipGP'):
+        self._gp, self._free, self._slot = gp, list(range(gp.pool_size)), {}
+
+    def bind(self, u: int):
+        slot = self._free.pop(0)
+        self._slot[u] = slot
+        self._gp._unit_signature.pop(slot, None)
+        return self._gp._load_output(slot, u)
+
+    def release(self, u: int):
+        slot = self._slot.pop(u)
+        self._gp._unit_signature.pop(slot, None)           # (the handle holds the optimum of ``u``; _select compares and re-sends as needed)
+        self._free.append(slot)
+
+
 class HipGP(GPR):
     """ARD-RBF GPs on one MI355X through librcgp.so.
 
@@ -300,14 +319,20 @@ class HipGP(GPR):
     UNIT_MEMORY_BUDGET: float = 96.0e9     #: bytes of HBM the pool's N x N work matrices (three per unit) may take together
 
     @property
-    def pool_size(self) -> int:
-        """P, the number of device handles the independent outputs are dealt to (1 for a covariant GP: one joint system)."""
+    def units_at_once(self) -> int:
+        """How many units of this GP's size the GPU is given at once: ``units_per_gpu`` (argument, RCGP_UNITS or by N) within what one
+        batched call takes and what fits in memory."""
         if self._is_covariant:
             return 1
         wanted = int(self._units_per_gpu) if self._units_per_gpu is not None else default_units_per_gpu(self._N)
         padded = -(-self._N // 128) * 128
         fits = int(self.UNIT_MEMORY_BUDGET // (3 * 8 * padded * padded))
-        return max(1, min(wanted, self._L, _lib.MAX_BATCH, fits))
+        return max(1, min(wanted, _lib.MAX_BATCH, fits))
+
+    @property
+    def pool_size(self) -> int:
+        """P, the number of device handles the independent outputs are dealt to (1 for a covariant GP: one joint system)."""
+        return max(1, min(self.units_at_once, self._L))
 
     def _unit(self, slot: int) -> _lib.RcGP:
         """The device handle of pool slot ``slot`` (created on first use: X uploaded once per unit)."""
@@ -438,17 +463,20 @@ class HipGP(GPR):
             self._reset_implementation()
             self._live_noise = np.array(fit['noise'], dtype=np.float64)        # the live model keeps its full Sigma (see _hyper_mo)
             return meta
-        # The reference fits output after output (gpr/models.py:360-361). Here the outputs of one pool-sized group are fitted together: their
-        # L-BFGS-B runs in lockstep, each round of evaluations one batched schedule on the GPU (gpr/optimize.py::fit_lbfgsb_batch).
-        fits, pool = [], self.pool_size
+        # The reference fits output after output (gpr/models.py:360-361). Here as many outputs as the pool has handles are fitted together:
+        # their L-BFGS-B runs in lockstep, each round of evaluations one batched schedule on the GPU (gpr/optimize.py::fit_lbfgsb_batch);
+        # with more outputs than handles the next output starts on the handle of one whose fit has ended.
         common = self._fit_options(method, meta, kernel_options, likelihood_options)
-        for first in range(0, self._L, pool):
-            units, starts = self._fit_units(range(first, min(first + pool, self._L)))
-            group = fit_lbfgsb_batch(units, starts, **common)
-            for fit in group:
-                if isinstance(fit, Exception):             # as in the reference, a failing output fails the calibration
-                    raise fit
-            fits.extend(group)
+        if self.pool_size >= self._L:
+            units, starts = self._fit_units(range(self._L))
+            fits = fit_lbfgsb_batch(units, starts, max_units=self.units_at_once, **common)
+        else:
+            slots = _PoolSlots(self)
+            fits = fit_lbfgsb_batch(None, self._fit_starts(range(self._L)), max_units=self.pool_size, bind=slots.bind, release=slots.release,
+                                    M=self._M, **common)
+        for fit in fits:
+            if isinstance(fit, Exception):                 # as in the reference, a failing output fails the calibration
+                raise fit
         return self._store_fits(fits, meta, kernel_options, likelihood_options)
 
     def _calibration_options(self, kwargs: Dict[str, Any]) -> Tuple[Dict[str, Any], Dict[str, Any], Dict[str, Any]]:
@@ -464,15 +492,21 @@ class HipGP(GPR):
         return dict(is_isotropic=self._is_isotropic, train_lengthscales=bool(kernel_options['lengthscales']['variant']),
                     train_variance=bool(kernel_options['variance']), train_noise=bool(likelihood_options['variance']), method=method, **meta)
 
-    def _fit_units(self, outputs) -> Tuple[list, list]:
-        """The pool's device handles loaded with ``outputs`` (at most ``pool_size`` of them, consecutive) and their start points."""
-        pool, units, starts = self.pool_size, [], []
+    def _fit_starts(self, outputs) -> list:
+        """The start point of every output in ``outputs``: its stored hyper-parameters."""
+        starts = []
         for l in outputs:
             lengthscales, variance, noise = self._hyper(l)
+            starts.append({'lengthscales': lengthscales[0] if self._is_isotropic else lengthscales, 'variance': variance, 'noise': noise})
+        return starts
+
+    def _fit_units(self, outputs) -> Tuple[list, list]:
+        """The pool's device handles loaded with ``outputs`` (at most ``pool_size`` of them, consecutive) and their start points."""
+        pool, units = self.pool_size, []
+        for l in outputs:
             units.append(self._load_output(l % pool, l))
             self._unit_signature.pop(l % pool, None)
-            starts.append({'lengthscales': lengthscales[0] if self._is_isotropic else lengthscales, 'variance': variance, 'noise': noise})
-        return units, starts
+        return units, self._fit_starts(outputs)
 
     def _store_fits(self, fits, meta, kernel_options, likelihood_options) -> Dict[str, Any]:
         """The side effects of MOGP.calibrate (gpr/models.py:362-372): meta.json with the optimiser results, the four parameter csv files."""
@@ -505,33 +539,33 @@ class HipGP(GPR):
             else:
                 groups.setdefault((gp.device, -(-gp.N // 128), gp.M), []).append(i)
         for members in groups.values():
-            per_call = max(1, _lib.MAX_BATCH // max(gps[i].L for i in members))
-            for first in range(0, len(members), per_call):
-                batch = members[first:first + per_call]
-                contexts, units, starts, owner = {}, [], [], []
-                for i in batch:
-                    gp = gps[i]
-                    try:
-                        options = gp._calibration_options(dict(kwargs))
-                        u, s = gp._fit_units(range(gp.L))
-                        common = gp._fit_options(method, *options)
-                    except Exception as failure:
-                        outcomes[i] = failure
-                        continue
-                    contexts[i] = options
-                    units += u
-                    starts += [common | start for start in s]     # (per GP: the stored meta.json may differ between folds)
-                    owner += [i] * len(u)
-                fits = fit_lbfgsb_batch(units, starts) if units else []
-                for i in contexts:
-                    mine = [fit for fit, o in zip(fits, owner) if o == i]
-                    failed = [fit for fit in mine if isinstance(fit, Exception)]
-                    try:
-                        if failed:
-                            raise failed[0]
-                        outcomes[i] = gps[i]._store_fits(mine, *contexts[i])
-                    except Exception as failure:
-                        outcomes[i] = failure
+            # every output of every member is a unit with a handle of its own; at most ``units_at_once`` of them are in flight, the
+            # next one starting when one has ended (``fit_lbfgsb_batch``)
+            at_once = min(gps[i].units_at_once for i in members)
+            contexts, units, starts, owner = {}, [], [], []
+            for i in members:
+                gp = gps[i]
+                try:
+                    options = gp._calibration_options(dict(kwargs))
+                    u, s = gp._fit_units(range(gp.L))
+                    common = gp._fit_options(method, *options)
+                except Exception as failure:
+                    outcomes[i] = failure
+                    continue
+                contexts[i] = options
+                units += u
+                starts += [common | start for start in s]     # (per GP: the stored meta.json may differ between folds)
+                owner += [i] * len(u)
+            fits = fit_lbfgsb_batch(units, starts, max_units=at_once) if units else []
+            for i in contexts:
+                mine = [fit for fit, o in zip(fits, owner) if o == i]
+                failed = [fit for fit in mine if isinstance(fit, Exception)]
+                try:
+                    if failed:
+                        raise failed[0]
+                    outcomes[i] = gps[i]._store_fits(mine, *contexts[i])
+                except Exception as failure:
+                    outcomes[i] = failure
         return outcomes
 
     def log_marginal_likelihood(self) -> np.ndarray:

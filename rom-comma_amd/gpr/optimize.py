@@ -275,22 +275,45 @@ class _SetulbRun:
                               success=(warnflag == 0), hess_inv=LbfgsInvHessProduct(s_[:n_corrs], y_[:n_corrs]))
 
 
-def _fit_reverse_communication(gps, problems, options, batch_lml_grad, max_units: int) -> list:
-    """Every unit's L-BFGS-B run advanced by ONE thread; each round of requests answered by batched evaluations."""
+def _fit_reverse_communication(gps, problems, options, batch_lml_grad, max_units: int, bind=None, release=None) -> list:
+    """Every unit's L-BFGS-B run advanced by ONE thread; each round of requests answered by one batched evaluation.
+
+    At most ``max_units`` runs are in flight: where there are more units, the next one STARTS when one in flight has ended (the runs need
+    different numbers of evaluations; a batch that waited for its slowest member before the next batch began would idle the slots of the
+    rest). ``bind(u)`` -- if given -- returns the device handle of unit ``u`` at that moment (a pool slot just freed, loaded with the unit's
+    targets) and ``release(u)`` hands it back; without them ``gps[u]`` is the unit's own handle throughout. A unit's fit is finished
+    (optimum set on its handle, LML read) as soon as its run ends, before its handle is released."""
+    from collections import deque
     from romcomma_amd._lib import NotPositiveDefiniteError
-    n = len(gps)
+    n = len(problems)
+    gps = list(gps) if gps is not None else [None] * n
     results: list = [None] * n
     runs: Dict[int, _SetulbRun] = {}
-    for u in range(n):
-        if not np.any(problems[u].mask):
-            results[u] = ('finish', None)
-            continue
+    waiting: deque = deque(range(n))
+    live: list = []
+
+    def end(u: int, outcome):                                # the run of unit ``u`` is over: its result, its handle back
         try:
-            runs[u] = _SetulbRun(problems[u].x0, **options)
+            results[u] = problems[u].finish(gps[u], outcome) if not isinstance(outcome, Exception) else outcome
         except Exception as failure:
             results[u] = failure
-    live = sorted(runs)
-    while live:
+        if release is not None and gps[u] is not None:
+            release(u)
+            gps[u] = None
+
+    while live or waiting:
+        while waiting and len(live) < max_units:             # start as many waiting units as there are free places
+            u = waiting.popleft()
+            try:
+                if bind is not None:
+                    gps[u] = bind(u)
+                if not np.any(problems[u].mask):             # nothing trains: the "fit" is the evaluation at the start point
+                    end(u, None)
+                    continue
+                runs[u] = _SetulbRun(problems[u].x0, **options)
+                live.append(u)
+            except Exception as failure:
+                end(u, failure)
         asking, points = [], {}
         for u in live:
             try:
@@ -299,34 +322,26 @@ def _fit_reverse_communication(gps, problems, options, batch_lml_grad, max_units
                     gps[u].set_hyper(*points[u][1])          # a point the library refuses fails ITS unit
                     asking.append(u)
                 else:
-                    results[u] = ('finish', runs[u].result())
+                    end(u, runs[u].result())
             except Exception as failure:
-                results[u] = failure
-        for first in range(0, len(asking), max_units):
-            part = asking[first:first + max_units]
+                end(u, failure)
+        live = []
+        if asking:
             try:
-                lml, grad, status = batch_lml_grad([gps[u] for u in part])
+                lml, grad, status = batch_lml_grad([gps[u] for u in asking])
             except Exception as failure:                     # a failed call fails every unit in it
-                for u in part:
-                    results[u] = failure
+                for u in asking:
+                    end(u, failure)
                 continue
-            for k, u in enumerate(part):
+            for k, u in enumerate(asking):
                 if int(status[k]) > 0:
-                    results[u] = NotPositiveDefiniteError(int(status[k]), f'rcgp_lml_grad_batch: matrix is not positive definite: leading minor {int(status[k])}')
+                    end(u, NotPositiveDefiniteError(int(status[k]),
+                                                    f'rcgp_lml_grad_batch: matrix is not positive definite: leading minor {int(status[k])}'))
                     continue
                 f, g = problems[u].loss_and_gradient(points[u][0], float(lml[k]), np.array(grad[k]))
                 runs[u].answer(f, g)
-        live = [u for u in asking if results[u] is None]
-    out = []
-    for u in range(n):
-        if isinstance(results[u], tuple):
-            try:
-                out.append(problems[u].finish(gps[u], results[u][1]))
-            except Exception as failure:
-                out.append(failure)
-        else:
-            out.append(results[u])
-    return out
+                live.append(u)
+    return results
 
 
 def _reverse_communication_ok() -> bool:
@@ -357,14 +372,19 @@ def _reverse_communication_ok() -> bool:
     return _RC_STATE['ok']
 
 
-def fit_lbfgsb_batch(gps: Sequence[Any], starts: Sequence[Dict[str, Any]], batch_lml_grad=None, max_units: Optional[int] = None,
-                     driver: Optional[str] = None, **common: Any) -> list:
+def fit_lbfgsb_batch(gps: Optional[Sequence[Any]], starts: Sequence[Dict[str, Any]], batch_lml_grad=None, max_units: Optional[int] = None,
+                     driver: Optional[str] = None, bind=None, release=None, M: Optional[int] = None, **common: Any) -> list:
     """``fit_lbfgsb`` for several units (``romcomma_amd._lib.RcGP`` of one device, equal M and padded size) at once.
 
     Args:
+        gps: one device handle per unit -- or None with ``bind`` / ``release``: FEWER handles than units, ``bind(u)`` returning the handle
+            unit ``u`` runs on from the moment it starts (a pool slot loaded with its targets) and ``release(u)`` taking it back when its
+            fit has ended; ``M`` = the handles' input dimension.
         starts: per unit the keyword arguments of ``fit_lbfgsb`` that differ between units (lengthscales, variance, noise, ...).
         common: keyword arguments shared by all units (is_isotropic, train_*, method, SciPy options).
         batch_lml_grad: the batched evaluation, ``romcomma_amd._lib.lml_grad_batch`` by default.
+        max_units: how many units are in flight at once (default and upper bound: what one batched call takes). With more units than that
+            the 'setulb' driver starts the next unit when one in flight has ended; the 'threads' driver takes them group after group.
         driver: 'setulb' (one thread driving SciPy's L-BFGS-B core by reverse communication), 'threads' (one ``minimize`` per unit in a
             thread of its own), or None = the environment variable RCGP_LOCKSTEP, else 'setulb' where it applies -- method L-BFGS-B, no
             callback, only the options ``_RC_OPTIONS``, and the self-check against ``minimize`` passed -- and 'threads' otherwise.
@@ -372,17 +392,35 @@ def fit_lbfgsb_batch(gps: Sequence[Any], starts: Sequence[Dict[str, Any]], batch
     Returns: per unit the dict ``fit_lbfgsb`` returns -- identical to what a fit of that unit alone returns -- or, for a unit whose
         fit raised (e.g. a matrix that is not positive definite), the exception; the other units are not affected by it.
     """
-    if len(gps) != len(starts):
+    n = len(starts)
+    if gps is None:
+        if bind is None or M is None:
+            raise ValueError('handles, or bind / release and M')
+    elif len(gps) != n:
         raise ValueError('one start per unit')
     if batch_lml_grad is None or max_units is None:
         from romcomma_amd import _lib
         batch_lml_grad = batch_lml_grad or _lib.lml_grad_batch
-        max_units = max_units or _lib.MAX_BATCH
-    if len(gps) == 1:                                         # nothing to meet with
-        try:
-            return [fit_lbfgsb(gps[0], **(dict(common) | dict(starts[0])))]
-        except Exception as failure:
-            return [failure]
+        max_units = min(max_units or _lib.MAX_BATCH, _lib.MAX_BATCH)
+    max_units = max(1, int(max_units))
+    handle_of = (lambda u: bind(u)) if bind is not None else (lambda u: gps[u])
+    give_back = release if (bind is not None and release is not None) else (lambda u: None)
+
+    def one_after_the_other(units) -> list:                   # nothing to meet with
+        out = []
+        for u in units:
+            try:
+                gp = handle_of(u)
+                try:
+                    out.append(fit_lbfgsb(gp, **(dict(common) | dict(starts[u]))))
+                finally:
+                    give_back(u)
+            except Exception as failure:
+                out.append(failure)
+        return out
+
+    if n == 1 or max_units == 1:
+        return one_after_the_other(range(n))
     if driver is None:
         import os
         driver = os.environ.get('RCGP_LOCKSTEP', 'setulb')
@@ -393,26 +431,45 @@ def fit_lbfgsb_batch(gps: Sequence[Any], starts: Sequence[Dict[str, Any]], batch
                     set(m) - set(keys) - {'method', 'callback'} <= _RC_OPTIONS for m in merged)
         options = [{k: v for k, v in m.items() if k in _RC_OPTIONS} for m in merged]
         if plain and all(o == options[0] for o in options) and _reverse_communication_ok():
-            problems = [_FitProblem(gp.M, m['lengthscales'], m['variance'], m['noise'], m.get('is_isotropic', False),
+            dims = [gp.M for gp in gps] if gps is not None else [int(M)] * n
+            problems = [_FitProblem(d, m['lengthscales'], m['variance'], m['noise'], m.get('is_isotropic', False),
                                     m.get('train_lengthscales', True), m.get('train_variance', True), m.get('train_noise', True))
-                        for gp, m in zip(gps, merged)]
-            return _fit_reverse_communication(list(gps), problems, {'maxiter': 5000, 'gtol': 1e-16} | options[0], batch_lml_grad, max_units)
-    lockstep = _Lockstep(gps, batch_lml_grad, max_units)
-    results: list = [None] * len(gps)
+                        for d, m in zip(dims, merged)]
+            return _fit_reverse_communication(gps, problems, {'maxiter': 5000, 'gtol': 1e-16} | options[0], batch_lml_grad, max_units,
+                                              bind, release)
+    results: list = [None] * n
+    for first in range(0, n, max_units):                      # the threads meet group by group
+        members = list(range(first, min(first + max_units, n)))
+        handles: Dict[int, Any] = {}
+        for u in members:
+            try:
+                handles[u] = handle_of(u)
+            except Exception as failure:
+                results[u] = failure
+        members = [u for u in members if u in handles]
+        if len(members) == 1:
+            try:
+                results[members[0]] = fit_lbfgsb(handles[members[0]], **(dict(common) | dict(starts[members[0]])))
+            except Exception as failure:
+                results[members[0]] = failure
+        elif members:
+            lockstep = _Lockstep([handles[u] for u in members], batch_lml_grad, max_units)
 
-    def run(u: int):
-        try:
-            results[u] = fit_lbfgsb(_LockstepUnit(lockstep, u, gps[u]), **(dict(common) | dict(starts[u])))
-        except BaseException as failure:                     # (the thread must leave the meeting point whatever happened)
-            results[u] = failure
-        finally:
-            lockstep.leave(u)
+            def run(k: int, u: int):
+                try:
+                    results[u] = fit_lbfgsb(_LockstepUnit(lockstep, k, handles[u]), **(dict(common) | dict(starts[u])))
+                except BaseException as failure:             # (the thread must leave the meeting point whatever happened)
+                    results[u] = failure
+                finally:
+                    lockstep.leave(k)
 
-    threads = [threading.Thread(target=run, args=(u,), name=f'rcgp-fit-{u}') for u in range(len(gps))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+            threads = [threading.Thread(target=run, args=(k, u), name=f'rcgp-fit-{u}') for k, u in enumerate(members)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        for u in handles:
+            give_back(u)
     for r in results:
         if isinstance(r, BaseException) and not isinstance(r, Exception):
             raise r                                           # KeyboardInterrupt and the like

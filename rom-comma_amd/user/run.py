@@ -102,6 +102,23 @@ def _each_fold(repo: Repository, shard_folds: bool, job: Callable[[Fold], list],
     return outcome
 
 
+def _folds_at_once(folds: int, L: int, places: int) -> int:
+    """How many folds are opened together when the GPU has ``places`` for (fold, output) units: the folds' units are dealt to the fewest
+    groups that overfill the places by no more than a quarter, and the groups are of equal size -- a group that overfills has its surplus
+    units start as places fall free (gpr/optimize.py::fit_lbfgsb_batch), which costs less than a small last group with the chip half
+    empty (measured: tools/README.md, folds_rule). One fold at a time when a single fold's outputs fill the places."""
+    import os
+    rule = os.environ.get('RCGP_FOLDS_RULE', 'balanced')
+    if L > places or folds < 2:
+        return 1
+    if rule == 'floor':
+        return max(1, places // L)
+    if rule == 'ceil':
+        return -(-places // L)
+    groups = max(1, -(-(4 * folds * L) // (5 * places)))
+    return max(1, min(-(-folds // groups), (5 * places) // (4 * L)))
+
+
 def _is_collector(shard_folds: bool) -> bool:
     """After a sharded pass: wait for every rank, then only rank 0 concatenates."""
     if dist.is_distributed() and shard_folds:
@@ -184,7 +201,7 @@ def gpr(name: str, repo: Repository, is_read: bool | None, is_covariant: bool | 
     at_once = 1
     if is_calibrated and len(repo.folds) > 1:
         at_once = int(units_per_gpu) if units_per_gpu is not None else default_units_per_gpu(repo.N)
-        at_once = max(1, at_once // max(int(repo.L), 1))          # (every output of a fold is a unit of its own)
+        at_once = _folds_at_once(len(_my_folds(repo, shard_folds)), max(int(repo.L), 1), at_once)
     _each_fold(repo, shard_folds, on_fold, on_fold_group, at_once)
     if _is_collector(shard_folds):
         per_model = {

@@ -255,6 +255,64 @@ def test_run_gpr_over_folds_at_once_writes_what_fold_after_fold_writes(gpu, tmp_
         assert (repos[1].folder / rel).read_bytes() == (repos[4].folder / rel).read_bytes(), rel
 
 
+def test_more_outputs_than_pool_slots_take_turns_on_the_slots(gpu, tmp_path):
+    """L = 5 outputs on a pool of two handles: the third output starts on the handle of whichever of the first two ends first, and so on
+    (fit_lbfgsb_batch with bind / release); the files are those of the one-after-the-other loop, and K_inv_Y / predict afterwards find
+    every output on its ``l mod P`` slot again."""
+    import pandas as pd
+    from romcomma_amd.data.storage import Fold, Repository
+    from romcomma_amd.gpr.models import HipGP
+    from romcomma_amd.user.sample import synthetic_outputs
+    N, M, L = 500, 3, 5
+    X, Y = synthetic_outputs(N + 40, M, L)
+    columns = pd.MultiIndex.from_tuples([('X', f'X.{m}') for m in range(M)] + [('Y', f'Y.{l}') for l in range(L)])
+    results = {}
+    for units in (2, 1):
+        repo = Repository.from_df(tmp_path / f'repo{units}', pd.DataFrame(np.concatenate([X, Y], axis=1), columns=columns)).into_K_folds(1, is_normalization_applicable=False)
+        gp = HipGP('gp', Fold(repo, 0), is_read=False, is_covariant=False, is_isotropic=False, units_per_gpu=units)
+        assert gp.pool_size == units and gp.units_at_once == units
+        before = gpu.stat()['batched_calls']
+        gp.calibrate()
+        batched_calls = gpu.stat()['batched_calls'] - before
+        frames = {name: pd.read_csv(gp.folder / name, index_col=0).to_numpy() for name in
+                  ('kernel/variance.csv', 'kernel/lengthscales.csv', 'likelihood/variance.csv', 'likelihood/log_marginal.csv')}
+        meta = (gp.folder / 'meta.json').read_text()
+        test_x = np.ascontiguousarray(gp.fold.test_x.values[:16])
+        results[units] = (frames, gp.K_inv_Y, gp.predict(test_x), len(gp._units), batched_calls, meta)
+        gp.close()
+    (fa, ka, pa, na, ca, ma), (fb, kb, pb, nb_, cb, mb) = results[2], results[1]
+    assert na == 2 and nb_ == 1 and ca > 20 and cb == 0
+    for name in fa:
+        assert np.array_equal(fa[name], fb[name]), name
+    assert ma == mb                                              # every output's OptimizeResult as printed, in output order
+    assert np.array_equal(ka, kb) and np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+
+
+def test_folds_whose_units_overfill_the_gpu_places(gpu, tmp_path):
+    """Three folds of L = 3 outputs with four places: ``run.gpr`` opens two folds at a time (six units, four in flight, the other two
+    starting as places fall free), then the third; byte for byte the files of fold after fold."""
+    import pandas as pd
+    from romcomma_amd.data.storage import Repository
+    from romcomma_amd.user import run
+    rng = np.random.default_rng(8)
+    X = rng.random((900, 3))
+    Y = np.stack([np.sin(2 * np.pi * X[:, l]) + 0.6 * X[:, (l + 1) % 3] ** 2 + 0.1 * X[:, (l + 2) % 3] for l in range(3)], axis=1)
+    Y += 0.05 * rng.standard_normal(Y.shape)
+    columns = pd.MultiIndex.from_tuples([('X', f'X.{m}') for m in range(3)] + [('Y', f'Y.{l}') for l in range(3)])
+    table = pd.DataFrame(np.concatenate([X, Y], axis=1), columns=columns)
+    repos = {}
+    for units in (1, 4):
+        repos[units] = Repository.from_df(tmp_path / f'units{units}', table).into_K_folds(-3, seed=2)
+        before = gpu.stat()['batched_calls']
+        assert run.gpr('gpr', repos[units], is_read=False, is_covariant=False, is_isotropic=None, units_per_gpu=units) == ['gpr.v.i', 'gpr.v.a']
+        assert (gpu.stat()['batched_calls'] > before + 20) == (units == 4)
+    files = [f'{model}/{name}' for model in ('gpr.v.i', 'gpr.v.a') for name in
+             ('kernel/lengthscales.csv', 'kernel/variance.csv', 'likelihood/variance.csv', 'likelihood/log_marginal.csv', 'test.csv',
+              'test_summary.csv')]
+    for rel in [f'fold.{k}/{f}' for k in range(3) for f in files] + [f'fold.{k}/{model}/meta.json' for k in range(3) for model in ('gpr.v.i', 'gpr.v.a')] + files:
+        assert (repos[1].folder / rel).read_bytes() == (repos[4].folder / rel).read_bytes(), rel
+
+
 def test_wide_designs_in_a_batch(gpu):
     """M = 80 > 64 (the chunked Gram / gradient kernels) through the batched entry: bit-identical to the single-handle call and
     equal to the oracle."""

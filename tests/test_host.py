@@ -246,3 +246,16 @@ def test_meta_json_is_replaced_atomically(tmp_path):
     assert json.loads((tmp_path / 'repo' / 'meta.json').read_text())['K'] == 3
     assert [p.name for p in (tmp_path / 'repo').iterdir() if p.name.endswith('.tmp')] == []
     assert (tmp_path / 'repo' / 'meta.json').read_text().startswith('{\n        "')                 # indent 8
+
+
+def test_folds_opened_together_on_one_gpu():
+    """run._folds_at_once: equal groups, the fewest that overfill the GPU's places by at most a quarter (profiles/r04_folds_rule.txt)."""
+    from romcomma_amd.user.run import _folds_at_once
+    assert _folds_at_once(2, 9, 16) == 2            # 18 units on 16 places: one group, two units wait for a place
+    assert _folds_at_once(4, 6, 16) == 2            # 24 units: two groups of 12, not 18 + 6
+    assert _folds_at_once(6, 5, 16) == 3            # 30 units: 15 + 15
+    assert _folds_at_once(8, 3, 16) == 4            # 24 units: 12 + 12, not 15 + 9
+    assert _folds_at_once(10, 2, 16) == 10          # 20 units on 16 places
+    assert _folds_at_once(5, 1, 2) == 2             # big folds, two places: never more than a quarter over
+    assert _folds_at_once(3, 9, 4) == 1             # one fold's outputs already overfill the places: fold after fold
+    assert _folds_at_once(1, 3, 16) == 1 and _folds_at_once(7, 1, 1) == 1

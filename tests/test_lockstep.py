@@ -119,3 +119,58 @@ def test_status_words_become_not_positive_definite_errors(driver):
         return lml, grad, status
     out = fit_lbfgsb_batch(units, [START] * 2, batch_lml_grad=second_unit_singular, max_units=8, driver=driver)
     assert isinstance(out[1], NotPositiveDefiniteError) and out[1].k == 17 and isinstance(out[0], dict)
+
+
+@DRIVERS
+def test_more_units_than_handles_take_turns_on_the_handles(driver):
+    """Seven units through three handles (bind / release: HipGP.calibrate with more outputs than pool slots): every fit is the fit the
+    unit has alone; never more than three handles out; with the setulb driver a waiting unit starts the moment a handle falls free, so
+    the device sees fewer calls than with groups of three that each wait for their slowest member."""
+    folds = [o.synthetic_fold(100 + 4 * k, 3, k=k) for k in range(7)]
+    alone = [fit_lbfgsb(Unit(*fold), **START) for fold in folds]
+    handles = [Unit(*folds[0]) for _ in range(3)]
+    free, held, most, order = list(range(3)), {}, [0], []
+
+    def bind(u):
+        slot = free.pop(0)
+        held[u] = slot
+        most[0] = max(most[0], len(held))
+        order.append(u)
+        handles[slot].X, handles[slot].y = folds[u]              # (the pool loads the unit's targets; here the whole fold)
+        return handles[slot]
+
+    def release(u):
+        free.append(held.pop(u))
+
+    calls = []
+    together = fit_lbfgsb_batch(None, [START] * 7, batch_lml_grad=batched(calls), max_units=3, driver=driver, bind=bind, release=release, M=3)
+    for a, b in zip(alone, together):
+        assert same_fit(a, b)
+    assert most[0] == 3 and not held and sorted(free) == [0, 1, 2] and sorted(order) == list(range(7)) and max(calls) <= 3
+    if driver == 'setulb':
+        evaluations = [a['nfev'] for a in alone]
+        grouped = sum(max(evaluations[first:first + 3]) for first in range(0, 7, 3))      # rounds of group-after-group lockstep
+        assert len(calls) < grouped and sum(calls) == sum(evaluations)
+    with pytest.raises(ValueError):
+        fit_lbfgsb_batch(None, [START] * 2, batch_lml_grad=batched([]), bind=bind)         # without M nobody knows the problem's size
+
+
+def test_a_unit_that_cannot_get_its_handle_fails_alone():
+    folds = [o.synthetic_fold(90, 3, k=k) for k in range(4)]
+    handle = [Unit(*folds[0]), Unit(*folds[0])]
+    free = [0, 1]
+    held = {}
+
+    def bind(u):
+        if u == 1:
+            raise MemoryError('no room')
+        held[u] = free.pop(0)
+        handle[held[u]].X, handle[held[u]].y = folds[u]
+        return handle[held[u]]
+
+    for driver in ('setulb', 'threads'):
+        out = fit_lbfgsb_batch(None, [START] * 4, batch_lml_grad=batched([]), max_units=2, driver=driver, bind=bind,
+                               release=lambda u: free.append(held.pop(u)), M=3)
+        assert isinstance(out[1], MemoryError) and all(isinstance(out[u], dict) for u in (0, 2, 3)) and sorted(free) == [0, 1]
+        alone = fit_lbfgsb(Unit(*folds[3]), **START)
+        assert same_fit(alone, out[3])
