@@ -107,12 +107,13 @@ class ClosedSobol(Calibrator):
         signature = (self.is_F_diagonal, np.asarray(self.F).tobytes(), np.asarray(self.Lambda).tobytes(), np.asarray(self.K_inv_Y).tobytes())
         shared = getattr(self.gp, '_sobol_memo', None)
         if shared is None or shared[0] != signature:
-            shared = (signature, {})
+            shared = (signature, {}, {}, {})
             try:
                 self.gp._sobol_memo = shared
             except AttributeError:                          # (an object that takes no attributes: keep the memo to this calibrator)
                 pass
         self._cache = shared[1]
+        self._shared_W = (shared[2], shared[3])             # ClosedSobolWithError: the covariances W behind the standard errors, per slice
 
     # ---- device calls
     def _V_many(self, slices: Sequence[Sequence[int]]) -> np.ndarray:
@@ -224,8 +225,9 @@ class ClosedSobolWithError(ClosedSobol):
         if not self.is_F_diagonal:
             raise NotImplementedError('If the MOGP kernel covariance is not diagonal, the Sobol error calculation is unstable.')   # :380-381
         M = self.M
-        self._W_diag: Dict[Tuple[int, int], np.ndarray] = {}
-        self._W_mixed: Dict[Tuple[int, int], np.ndarray] = {}
+        # (shared like the conditional variances: one device pass per output pair yields the error terms of EVERY first-order / closed /
+        # total slice, and the calibrators of the three kinds on one gp would otherwise each repeat all L^2 of them)
+        self._W_diag, self._W_mixed = self._shared_W
         self.V[4] = self.V[2] * self.V[2]                              # :383
         canonical = [(m, m + 1) for m in range(M)] + [(0, m + 1) for m in range(M)] + [(m + 1, M) for m in range(M)]
         self._error_matrices(canonical)

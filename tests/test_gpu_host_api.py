@@ -34,7 +34,7 @@ def assert_T_matches(T_got, T_ref, V4, W_scale, what=''):
     assert np.all(excess <= 0), f'{what}: Q off by up to {np.max(np.abs(Q_got - Q_ref)):.3e} on a W scale of {W_scale:.3e}'
 
 
-def test_run_gpr_gsa_end_to_end(gpu, tmp_path):
+def test_run_gpr_gsa_end_to_end(gpu, tmp_path, monkeypatch):
     from romcomma_amd.data.storage import Fold
     from romcomma_amd.gpr.models import MOGP
     from romcomma_amd.gsa.models import GSA, Sobol
@@ -100,6 +100,9 @@ def test_run_gpr_gsa_end_to_end(gpu, tmp_path):
     # ---- standard errors (ClosedSobolWithError): partial and full T, all kinds, against the reduced-form oracle
     from oracle.sobol_error_oracle import ClosedSobolWithErrorOracle
     Kc = np.stack([o.k_cho(X, Y[:, l], ell[l], var[l], noise[l]) if False else o.k_cho(X, ell[l], var[l], noise[l]) for l in range(2)])
+    device_passes = []
+    plain_error_terms = gpu.RcGP.sobol_error_terms
+    monkeypatch.setattr(gpu.RcGP, 'sobol_error_terms', lambda self, *args, **kw: device_passes.append(1) or plain_error_terms(self, *args, **kw))
     for partial in (True, False):
         err = ClosedSobolWithErrorOracle(X, alpha[:, None, :], var[None, :], ell, Kc, is_T_partial=partial)
         for kind, okind in ((GSA.Kind.FIRST_ORDER, o.FIRST_ORDER), (GSA.Kind.CLOSED, o.CLOSED), (GSA.Kind.TOTAL, o.TOTAL)):
@@ -118,6 +121,10 @@ def test_run_gpr_gsa_end_to_end(gpu, tmp_path):
             assert_T_matches(got_T, T, err.V[4], W_scale, f'{kind.name} partial={partial}')
             assert sobol.results['T'].shape == (2, 2, 3 if partial else 4)
             assert (sobol.folder / 'T.csv').exists() and (sobol.folder / 'W.csv').exists()
+    # one device pass per output pair serves every slice of every kind, partial or not: the six calibrators above share it through the gp
+    # (the reference recomputes all of it per kind: gsa/models.py:205, user/run.py:141-147)
+    assert len(device_passes) == 2 * 2
+    monkeypatch.undo()
     gp.close()
     names = run.gsa('gpr', repo, is_covariant=False, is_isotropic=False, kinds=GSA.Kind.CLOSED, is_error_calculated=True, is_T_partial=False)
     assert [str(n) for n in names] == ['gpr.v.a/gsa/closed']
