@@ -28,11 +28,12 @@ def _thetas(M, n):
     return [(ell * (1.0 + 0.07 * u), var * (1.0 + 0.2 * u), noise * (1.0 + u)) for u in range(n)]
 
 
-@pytest.mark.parametrize('sizes', [(700, 650, 768), (1500, 1500), (2100, 2050, 2176, 2049, 2100)])
+@pytest.mark.parametrize('sizes', [(700, 650, 768), (1500, 1500), (2100, 2050, 2176, 2049, 2100), (5000, 5100, 4999)])
 def test_batch_is_bit_identical_to_the_single_handle_call(gpu, sizes):
     """Units of different N under one padded size, batches of every size up to len(sizes): LML, gradient and K_inv_Y equal to the last bit
     to what each handle returns on its own. (The factorisation's schedule, the tile shapes of the L^-1 levels and the launch a unit
-    shares do not enter a unit's arithmetic: every tile adds up its k-slabs in one fixed order.)"""
+    shares do not enter a unit's arithmetic: every tile adds up its k-slabs in one fixed order.) At N = 5000 a batch runs six outer panels of
+    512 columns ahead of a 16-block tail while the single call is all tail: two different schedules, the same bits."""
     M = 4
     gps, _ = _units(gpu, sizes, M)
     thetas = _thetas(M, len(sizes))
@@ -57,7 +58,7 @@ def test_batch_is_bit_identical_to_the_single_handle_call(gpu, sizes):
         gp.close()
 
 
-@pytest.mark.parametrize('sizes', [(520, 600), (900, 1000, 1024)])
+@pytest.mark.parametrize('sizes', [(520, 600), (900, 1000, 1024), (4200, 4224)])       # (the last: a batched schedule with outer panels)
 def test_batch_against_oracle(gpu, sizes):
     M = 5
     gps, data = _units(gpu, sizes, M, seed_offset=3)
@@ -82,15 +83,17 @@ def test_batch_against_oracle(gpu, sizes):
         gp.close()
 
 
-def test_a_unit_that_is_not_positive_definite_leaves_the_others_alone(gpu):
+@pytest.mark.parametrize('N,twin', [(900, 700), (3000, 700), (3000, 2900)])
+def test_a_unit_that_is_not_positive_definite_leaves_the_others_alone(gpu, N, twin):
     """Duplicate rows with zero noise on unit 1 (TensorFlow raises InvalidArgumentError from tf.linalg.cholesky there, gpr/models.py:439):
     its status word names a leading minor, its numbers are NaN, units 0 and 2 get exactly what they get alone; afterwards the bad unit
-    is usable again."""
-    M, N = 3, 900
+    is usable again. N = 3000: the batched schedule runs outer panels ahead of its tail, and the unit fails inside the first panel (row
+    700) or inside the tail (row 2900) while the others' panels go on."""
+    M = 3
     gps, data = _units(gpu, (N, N, N), M, seed_offset=20)
     X1, y1 = data[1]
     X1 = X1.copy()
-    X1[700] = X1[30]
+    X1[twin] = X1[30]
     gps[1].close()
     gps[1] = gpu.RcGP(X1, y1)
     thetas = _thetas(M, 3)
