@@ -532,6 +532,43 @@ def test_sobol_error_terms_many_dimensions(gpu):
     gp.close()
 
 
+def test_sobol_error_terms_at_size(gpu):
+    """The standard-error ingredients at N = 4096 (32 x 32 pair tiles per form, |L^-1 f|^2 through the full-size L^-1): the output itself
+    and a second output, a first-order, a closed, a complement and an arbitrary slice, against the reduced-form oracle (four N x N pair
+    matrices per slice on the host: the reason this is not run at N = 16384)."""
+    from oracle import sobol_error_oracle as e
+    N, M = 4096, 5
+    X, y = o.synthetic_fold(N, M)
+    ell, var, noise = o.bench_hyper(M)
+    ell_a, var_a, noise_a = ell * 1.3, 0.8, 0.02
+    y_a = np.cos(X[:, 0]) + 0.5 * X[:, 1] * X[:, 2] + 0.05 * np.random.default_rng(4).standard_normal(N)      # a second output on the same design
+    y_a = (y_a - y_a.mean()) / y_a.std()
+    alpha = np.stack([o.k_inv_y(X, y_a, ell_a, var_a, noise_a), o.k_inv_y(X, y, ell, var, noise)])
+    Kc = [None, o.k_cho(X, ell, var, noise)]                                   # (only output b's factor is ever used)
+    ells, F = np.stack([ell_a, ell]), np.array([var_a, var])
+    phi, ups = 1 / (ells * ells + 1), 1 / (ells * ells + 2)
+    g0 = (F * np.sqrt(np.prod(ells * ells * phi, axis=1)))[:, None] * np.exp(-0.5 * np.einsum('lm,nm->ln', phi, X ** 2))
+    g = g0 * alpha
+    g = g - g.mean(axis=1, keepdims=True)                                      # gsa/calibrators.py:90
+    pre = F * np.sqrt(np.prod(ells * ells * ups, axis=1))                      # :384
+    slices = [(2, 3), (0, 3), (3, M), (1, 4)]
+    gp = gpu.RcGP(X, y)
+    gp.set_hyper(ell, var, noise)
+    got_self = gp.sobol_error_terms(slices)
+    got_pair = gp.sobol_error_terms(slices, ell_a, var_a, alpha[0])
+    gp.close()
+    for a, got in ((1, got_self), (0, got_pair)):
+        want = np.array([e.error_terms_pair(X, a, 1, g0, g, phi, ups, pre, Kc, sl) for sl in slices])          # [slice][phi_d, psi_d, phi_m, psi_m]
+        # every ingredient is a sum of N^2 terms of both signs (g is centred): for a slice the output hardly depends on -- here x_2 alone
+        # for the second output, 4e-8 where sum |terms| = 6e6 -- the value carries the rounding of that sum: numpy's fp64 gives 3.98796e-8, the
+        # same sum in np.longdouble 3.98792e-8, the GPU's tile-wise sums 3.98791e-8 (the oracle is the noisier side here). Held to 1e-6 of
+        # the ingredient's largest value over the slices, i.e. on the scale W = phi - psi and T are formed on (tests/test_gpu_host_api.py)
+        for k in range(4):
+            scale = np.max(np.abs(want[:, k]))
+            for s, sl in enumerate(slices):
+                assert got[k][s] == pytest.approx(want[s, k], rel=1e-6, abs=1e-6 * scale), (a, sl, k, scale)
+
+
 def test_multi_stream_cholesky_is_bitwise_reproducible(gpu):
     """The look-ahead factorisation runs on six streams ordered by events only. Every tile is written by kernels in one fixed order,
     so repeated factorisations must agree BIT FOR BIT; a missing dependency would show up here as run-to-run differences."""
