@@ -288,7 +288,9 @@ def test_exp_accuracy_through_gram(gpu):
 # BASELINE.json sizes: size-independent properties (the oracle cannot run these in seconds)
 # --------------------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize('N,M', [(8192, 5), (16384, 10), (28672, 20)])      # BASELINE configs[1], [2] and one fold of [4]
+# BASELINE configs[1], [2] and one fold of [4]; N = 49152: beyond every configuration -- Np^2 > 2^31 elements, so every offset that is not
+# 64-bit shows (58 GB of work matrices, 1.2e14 flops per evaluation: 8 s for the whole case)
+@pytest.mark.parametrize('N,M', [(8192, 5), (16384, 10), (28672, 20), (49152, 6)])
 def test_full_size_properties(gpu, N, M):
     X, y = o.synthetic_fold(N, M)
     ell, var, noise = o.bench_hyper(M)
